@@ -1,0 +1,157 @@
+"""Host-side input builders vs golden vectors from the reference (CPU only)."""
+from __future__ import annotations
+
+import json
+
+import numpy as np
+import pytest
+
+from golden_utils import GOLDEN, edges_from_json
+from qpsim_amd import initial_conditions as ic
+from qpsim_amd import precompute, tables
+from qpsim_amd.geometry import create_intrinsic_geometry, extract_edge_segments
+from qpsim_amd.models import (
+    BoundaryCondition,
+    ExternalGenerationSpec,
+    InitialConditionSpec,
+    SimulationParameters,
+    normalize_collision_solver_name,
+)
+from qpsim_amd.safe_eval import compile_safe_expression
+
+
+def _z(name):
+    z = np.load(GOLDEN / name, allow_pickle=False)
+    return z, json.loads(str(z["meta_json"]))
+
+
+def test_tables_match_reference():
+    z, meta = _z("tables.npz")
+    for tag, m in meta.items():
+        E, dE = tables.build_energy_grid(m["gap"], m["fmin"], m["fmax"], m["ne"])
+        assert np.array_equal(E, z[f"{tag}_E"]) and dE == float(z[f"{tag}_dE"])
+        assert np.array_equal(tables.dynes_density_of_states(E, m["gap"], m["gamma"]), z[f"{tag}_rho"])
+        assert np.array_equal(tables.bcs_density_of_states(E, m["gap"]), z[f"{tag}_bcs"])
+        assert np.array_equal(tables.thermal_qp_weights(E, m["gap"], m["T_b"], m["gamma"]), z[f"{tag}_qp_weights"])
+        assert np.array_equal(tables.recombination_kernel_base(E, m["gap"], m["tau_r"], m["T_c"]), z[f"{tag}_Kr0"])
+        assert np.array_equal(tables.scattering_kernel_base(E, m["gap"], m["tau_s"], m["T_c"]), z[f"{tag}_Ks0"])
+        assert np.array_equal(tables.recombination_kernel(E, m["gap"], m["tau_r"], m["T_c"], m["T_b"]), z[f"{tag}_Kr"])
+        assert np.array_equal(tables.scattering_kernel(E, m["gap"], m["tau_s"], m["T_c"], m["T_b"]), z[f"{tag}_Ks"])
+        om, idx_d, idx_s, sg = tables.build_phonon_frequency_map(E)
+        assert np.array_equal(om, z[f"{tag}_omega"])
+        assert np.array_equal(idx_d, z[f"{tag}_idx_diff"]) and np.array_equal(idx_s, z[f"{tag}_idx_sum"])
+        assert np.array_equal(sg, z[f"{tag}_sign"])
+        assert np.array_equal(tables.thermal_phonon_occupation(om, m["T_b"]), z[f"{tag}_nph"])
+        assert np.array_equal(tables.integration_widths_from_centers(om, fallback_width=dE), z[f"{tag}_widths"])
+    E1, dE1 = tables.build_energy_grid(180.0, 1.5, 1.5, 1)
+    assert np.array_equal(E1, z["single_E"]) and dE1 == float(z["single_dE"])
+    assert np.array_equal(tables.integration_widths_from_centers(np.array([3.0]), fallback_width=0.7), z["widths_single"])
+
+
+def test_table_argument_errors():
+    with pytest.raises(ValueError):
+        tables.build_energy_grid(0.0, 1, 2, 4)
+    with pytest.raises(ValueError):
+        tables.build_energy_grid(1.0, 2, 2, 4)
+    with pytest.raises(ValueError):
+        tables.integration_widths_from_centers(np.array([1.0, 1.0]))
+    with pytest.raises(ValueError):
+        tables.thermal_phonon_occupation(np.array([-1.0]), 0.1)
+
+
+def test_edge_segments_match_reference_ids_and_faces():
+    z, meta = _z("geometry_edges.npz")
+    for name, ref_edges in meta.items():
+        mine = extract_edge_segments(z[f"{name}_mask"])
+        ref = edges_from_json(ref_edges)
+        assert len(mine) == len(ref), name
+        for a, b in zip(mine, ref):
+            assert (a.edge_id, a.normal, a.x0, a.y0, a.x1, a.y1) == (b.edge_id, b.normal, b.x0, b.y0, b.x1, b.y1), name
+            assert [(f.row, f.col, f.direction) for f in a.faces] == [(f.row, f.col, f.direction) for f in b.faces]
+    assert np.array_equal(np.asarray(create_intrinsic_geometry().mask, dtype=bool), z["intrinsic_64x120_mask"])
+
+
+def test_models_validation_rules():
+    assert normalize_collision_solver_name(" Fischer_Catelani_Local ") == "fischer_catelani_local"
+    with pytest.raises(ValueError):
+        normalize_collision_solver_name("boltzphlow_relaxation")
+    with pytest.raises(ValueError):
+        BoundaryCondition("dirichlet").validate()
+    with pytest.raises(ValueError):
+        BoundaryCondition("periodic").validate()
+    BoundaryCondition(" Reflective ").validate()
+    p = SimulationParameters(diffusion_coefficient=6.0, dt=0.1, total_time=1.0, mesh_size=1.0, tau_0=300.0)
+    assert (p.tau_s, p.tau_r, p.tau_0) == (300.0, 300.0, 300.0)
+    p = SimulationParameters(diffusion_coefficient=6.0, dt=0.1, total_time=1.0, mesh_size=1.0, tau_s=250.0, tau_r=900.0)
+    assert p.tau_0 == 575.0
+    with pytest.raises(ValueError):
+        SimulationParameters(diffusion_coefficient=6.0, dt=0.1, total_time=1.0, mesh_size=1.0,
+                             external_generation=ExternalGenerationSpec(mode="constant", rate=-1.0))
+    with pytest.raises(ValueError):
+        SimulationParameters(diffusion_coefficient=6.0, dt=0.1, total_time=1.0, mesh_size=1.0, energy_gap=180.0,
+                             num_energy_bins=1)
+
+
+def test_safe_eval_accepts_and_rejects():
+    f = compile_safe_expression("return np.where(x > 0.5, params['a'], params.get('b', 2.0)) + math.pi * 0",
+                                variable_names=("x", "params"))
+    assert np.array_equal(f(x=np.array([0.2, 0.8]), params={"a": 1.0}), np.array([2.0, 1.0]))
+    assert compile_safe_expression("", variable_names=())() == 0.0
+    for bad in ("__import__('os')", "x.__class__", "np.linalg.inv(x)", "open('f')", "[i for i in x]", "lambda: 1",
+                "x.sum()", "np.load('a')", "math[0]", "f(**params)", "x = 1", "np.random.rand(3)"):
+        with pytest.raises(ValueError):
+            compile_safe_expression(bad, variable_names=("x", "params"))
+    with pytest.raises(ValueError):
+        compile_safe_expression("x + 1", variable_names=("x",))()
+
+
+def test_precompute_matches_reference():
+    z, meta = _z("host_side.npz")
+    mask = z["pre_mask"]
+    edges = edges_from_json(meta["pre_edges"])
+    bcs = {e.edge_id: BoundaryCondition("reflective") for e in edges}
+    for tag in ("uni", "non"):
+        d = dict(meta[f"pre_{tag}"])
+        d["external_generation"] = ExternalGenerationSpec(**d["external_generation"])
+        p = SimulationParameters(**d)
+        for kern in (0, 1):
+            pre = precompute.precompute_arrays(mask, edges, bcs, p, include_collision_kernels=bool(kern))
+            keys = {k.split("__", 1)[1] for k in z.files if k.startswith(f"pre_{tag}_{kern}__")}
+            assert set(pre.keys()) == keys
+            for k in keys:
+                ref = z[f"pre_{tag}_{kern}__{k}"]
+                assert np.allclose(np.asarray(pre[k], dtype=float), ref.astype(float), rtol=1e-14, atol=0), (tag, kern, k)
+            assert precompute.validate_precomputed(pre, p, mask) is None
+            broken = dict(pre)
+            broken.pop("D_array")
+            assert "D_array" in precompute.validate_precomputed(broken, p, mask)
+        p2 = SimulationParameters(**{**d, "diffusion_coefficient": 7.0})
+        assert "diffusion_coefficient" in precompute.validate_precomputed(pre, p2, mask)
+    assert precompute._mask_hash(mask) == float(z["mask_hash"])
+    assert precompute._gap_expression_hash("return 180 + 20 * x") == float(z["gap_expr_hash"])
+    with pytest.raises(ValueError):
+        precompute.precompute_arrays(mask, edges, bcs, SimulationParameters(
+            diffusion_coefficient=6.0, dt=0.1, total_time=0.1, mesh_size=1.0, energy_gap=180.0,
+            energy_max_factor=3.0, num_energy_bins=8, gap_expression="np.nan"))
+
+
+def test_initial_condition_builders_match_reference():
+    z, meta = _z("host_side.npz")
+    mask, E, om = z["ic_mask"], z["ic_E"], z["ic_omega"]
+    for nm in ("gauss", "uniform", "point_in", "point_hole", "custom", "default"):
+        got = ic.build_initial_field(mask, InitialConditionSpec(**meta[f"ic_{nm}"]))
+        assert np.allclose(got, z[f"ic_field_{nm}"], rtol=1e-15, atol=0), nm
+    for nm in ("fd", "fd_default_T", "uni", "cust"):
+        got = ic.build_initial_energy_weights(E, 180.0, 0.1, InitialConditionSpec(**meta[f"icw_{nm}"]), 0.2)
+        assert np.allclose(got, z[f"ic_ew_{nm}"], rtol=1e-15, atol=0), nm
+    assert ic.build_initial_energy_weights(E, 180.0, 0.1, InitialConditionSpec(), 0.2) is None
+    for nm in ("be", "be_bath", "uni", "full"):
+        got = ic.build_initial_phonon_energy_state(mask, om, InitialConditionSpec(**meta[f"icp_{nm}"]), 0.15)
+        assert np.allclose(got, z[f"ic_ph_{nm}"], rtol=1e-15, atol=0), nm
+    got = ic.build_initial_qp_energy_state(mask, E, InitialConditionSpec(**meta["icq_full"]))
+    assert np.allclose(got, z["ic_qp_full"], rtol=1e-15, atol=0)
+    assert ic.build_initial_qp_energy_state(mask, E, InitialConditionSpec()) is None
+    assert np.allclose(ic.evaluate_gap_expression("return 180 + 20 * x - 3 * y", mask, 180.0), z["gap_values_expr"], rtol=1e-15)
+    assert np.array_equal(ic.evaluate_gap_expression("", mask, 180.0), z["gap_values_default"])
+    with pytest.raises(ValueError):
+        ic.evaluate_gap_expression("return x - 0.5", mask, 180.0)
