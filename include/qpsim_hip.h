@@ -1,0 +1,154 @@
+/*
+ * qpsim_hip.h -- C ABI of libqpsim_hip.so: the MI355X (gfx950) kernels behind the time loop of
+ * qpsim.solver.run_2d_crank_nicolson (reference: /root/reference/qpsim/solver.py, cited per entry).
+ *
+ * The reference is pure Python and has no FFI of its own; the boundary it exposes for this path is one
+ * Python function plus the step helpers.  This header is the binding a maintainer of the reference would
+ * call from Python (ctypes) in place of the NumPy/SciPy bodies cited below.
+ *
+ * Conventions
+ *   - Plain C types only: device pointers (HIP global memory), sizes, scalars, and a hipStream_t passed as
+ *     void*.  No torch types.  All real data is IEEE fp64.
+ *   - Every call returns 0 on success or a negative qp_status code; qp_last_error() gives the message of the
+ *     last failure on the calling thread.  Nothing throws across the boundary.
+ *   - Calls only enqueue work on `stream`; they never allocate, free or synchronise (graph-capture safe),
+ *     except the *_create / *_destroy plan calls.
+ *   - Fields live on the FULL ny x nx grid, row-major, one contiguous "plane" of ncell = ny*nx doubles per
+ *     field; cells outside the geometry mask are kept at 0.  A batch is `nfield` consecutive planes
+ *     (energy bins, ensemble members x bins).  The reference packs only interior cells
+ *     (solver.py:53-58,1281-1285); the host layer converts at the boundary.
+ *
+ * Geometry / operator encoding (shared by every field of a problem)
+ *   flags[ncell] (uint8): bit0 link to x-1, bit1 link to x+1, bit2 link to y-1, bit3 link to y+1,
+ *                         bit4 cell is interior.  A link exists when both cells are interior.
+ *   ex, ey[ncell]: boundary-face diagonal terms of the x- / y-faces of the cell in units of 1/dx^2:
+ *                  absorbing 2, dirichlet 2, robin beta*dx, reflective/neumann 0     (solver.py:112-149)
+ *   sx, sy[ncell]: boundary-face source terms in units of 1/dx^2:
+ *                  dirichlet 2g, neumann q*dx, robin gamma*dx                          (solver.py:112-149)
+ *   Diffusion coefficient of field b: scalar dcoef[b] (uniform gap) or plane dfield[b*ncell + p]
+ *   (non-uniform gap: harmonic-mean face values 2 Dp Dq / max(Dp+Dq, 1e-30), solver.py:235-321).
+ *   With r = dt/(2 dx^2) the directional operators are
+ *      (r Lx u)_p = r [ w-(u_{p-1}-u_p) + w+(u_{p+1}-u_p) - ex_p D_p u_p ],   source r D_p sx_p   (same in y).
+ */
+#ifndef QPSIM_HIP_H
+#define QPSIM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum qp_status {
+  QP_OK = 0,
+  QP_ERR_INVALID_ARGUMENT = -1,
+  QP_ERR_LAUNCH = -2,
+  QP_ERR_UNSUPPORTED = -3,
+  QP_ERR_ALLOC = -4
+} qp_status;
+
+#define QP_FLAG_LINK_XM 1u
+#define QP_FLAG_LINK_XP 2u
+#define QP_FLAG_LINK_YM 4u
+#define QP_FLAG_LINK_YP 8u
+#define QP_FLAG_ACTIVE 16u
+
+/* Library version (major*10000 + minor*100 + patch) and last error text of this thread. */
+int qp_version(void);
+const char* qp_last_error(void);
+
+/* Geometry + per-field diffusivity description passed to the general diffusion kernels. */
+typedef struct qp_grid_desc {
+  int32_t ny, nx;          /* grid extent; ncell = ny*nx */
+  int32_t nfield;          /* planes in the batch */
+  const uint8_t* flags;    /* [ncell] */
+  const double* ex;        /* [ncell] */
+  const double* ey;        /* [ncell] */
+  const double* sx;        /* [ncell] */
+  const double* sy;        /* [ncell] */
+  const double* dcoef;     /* [nfield] uniform diffusivity per field, or NULL */
+  const double* dfield;    /* [nfield*ncell] diffusivity planes, or NULL (exactly one of dcoef/dfield) */
+} qp_grid_desc;
+
+/*
+ * out = c0*u + cx*(r Lx u) + cy*(r Ly u) + cs*(r D (sx+sy)) + cr*rin          (rin may be NULL when cr == 0)
+ *
+ * One pass of the 5-point operator of solver.py:152-212 / :235-321 split by direction.  With
+ * (c0,cx,cy,cs,cr) = (1,0,1,1,0) it is the explicit half of the first ADI sweep, (1,1,1,2,0) the
+ * Crank-Nicolson right-hand side B u + dt D source of solver.py:1440,1451,1554, and (-1,1,1,0,1) the residual
+ * rin - (I - r L) u used by the exact-CN iteration.  r = dt/(2 dx^2).
+ */
+int qp_stencil_combine(const qp_grid_desc* g, double r, const double* u, const double* rin, double* out,
+                       double c0, double cx, double cy, double cs, double cr, void* stream);
+
+/*
+ * Implicit sweep: solve (I - r L_dir) x = rhs along every grid line of every field (dir 0 = x, 1 = y).
+ * Replaces `lu.solve(rhs)` of solver.py:1441,1452,1555 one direction at a time.  `scratch` holds
+ * 2*nfield*ncell doubles.  rhs and x may alias.  General (masked / variable-D) path: Thomas per line.
+ */
+int qp_implicit_sweep(const qp_grid_desc* g, double r, int dir, const double* rhs, double* x, double* scratch,
+                      void* stream);
+
+/*
+ * Collision tables for qp_collision_step (all device pointers).  Built on the host exactly as
+ * solver.py:463-490 (kernels), :324-342 (rho), :668-683 (phonon bin maps); `cls` selects the per-pixel
+ * gap class (solver.py:1203-1232 copies per-pixel tables; here only one table set per distinct gap is kept).
+ */
+typedef struct qp_collision_tables {
+  int32_t ne;              /* quasiparticle energy bins */
+  int32_t nw;              /* phonon bins */
+  int32_t nclass;          /* distinct gap classes (1 = uniform) */
+  const double* kr0;       /* [nclass][ne][ne] or NULL when recombination is off */
+  const double* ks0;       /* [nclass][ne][ne] or NULL when scattering is off */
+  const double* rho;       /* [nclass][ne] */
+  const int32_t* idx_diff; /* [ne][ne] phonon bin of |Ei-Ej| */
+  const int32_t* idx_sum;  /* [ne][ne] phonon bin of Ei+Ej */
+  const int8_t* sign;      /* [ne][ne] sign(Ei-Ej) */
+  const int32_t* cls;      /* [ncell] gap class per cell, or NULL when nclass == 1 */
+} qp_collision_tables;
+
+/*
+ * One local coupled quasiparticle-phonon collision update of every interior cell
+ * (solver.py:703-791 per pixel, :794-875 the pixel loops).  state_in [ne][ncell] and phonon [nw][ncell]
+ * are read as the OLD values; the new quasiparticle density goes to state_out (must not alias state_in),
+ * phonons are updated in place when update_phonons != 0.  ph_scratch holds 2*nw*ncell doubles.
+ * Cells whose flags lack QP_FLAG_ACTIVE are copied through unchanged.
+ */
+int qp_collision_step(const qp_collision_tables* t, const uint8_t* flags, int64_t ncell, const double* state_in,
+                      double* state_out, double* phonon, double* ph_scratch, double dE, double dt,
+                      int enable_recombination, int enable_scattering, int update_phonons, void* stream);
+
+/*
+ * state[f][p] += amount for every interior cell of `nfield` planes (constant / pulse external generation,
+ * solver.py:910-916,1464), or state += scale * g[f][p] (custom generation evaluated on the host).
+ */
+int qp_add_constant(const uint8_t* flags, int64_t ncell, int32_t nfield, double* state, double amount, void* stream);
+int qp_add_scaled(int64_t n, double* state, const double* g, double scale, void* stream);
+
+/*
+ * Pauli-guard statistics over state[ne][ncell] (solver.py:967-996): occupation f = n / rho where rho > 1e-30.
+ * out_vals[0] = max f, out_idx[0] = its linear index ie*ncell + p (first in C order on ties),
+ * out_idx[1] = first linear index with rho <= 1e-30 and n > density_floor, or -1.
+ * workspace: qp_pauli_workspace_bytes() bytes.  Results land in device memory (copy them back yourself).
+ */
+int64_t qp_pauli_workspace_bytes(void);
+int qp_pauli_stats(const double* state, const double* rho, const int32_t* cls, const uint8_t* flags, int32_t ne,
+                   int32_t nclass, int64_t ncell, double density_floor, void* workspace, double* out_vals,
+                   int64_t* out_idx, void* stream);
+
+/* out[p] = dE * sum_i state[i][p]  (energy integral of solver.py:1367,1480; sequential in i). */
+int qp_energy_integrate(const double* state, int32_t ne, int64_t ncell, double dE, double* out, void* stream);
+
+/* out[p] = sum_i state[i][p] * weights[i]  (phonon integrated occupation, solver.py:1358). */
+int qp_weighted_sum(const double* state, const double* weights, int32_t n, int64_t ncell, double* out, void* stream);
+
+/* out_val[0] = max_p |a[p]| over n doubles (convergence check of the exact-CN iteration). workspace as above. */
+int qp_absmax(const double* a, int64_t n, void* workspace, double* out_val, void* stream);
+
+/* y[i] += alpha * x[i] */
+int qp_axpy(int64_t n, double alpha, const double* x, double* y, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QPSIM_HIP_H */

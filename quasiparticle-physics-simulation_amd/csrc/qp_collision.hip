@@ -1,0 +1,150 @@
+// Local coupled quasiparticle-phonon collision update (reference solver.py:703-791), one thread per cell.
+//
+// Generic table-driven kernel: any NE, any phonon-bin map, per-cell gap classes.  State planes are
+// [bin][cell], so every load/store of a plane element is coalesced across the wave.  The per-cell phonon
+// accumulators a, b live in a scratch plane set [2][nw][ncell] (each thread only touches its own column).
+#include "qp_common.h"
+
+namespace qp {
+
+struct CollView {
+  int ne, nw, nclass;
+  const double* kr0;
+  const double* ks0;
+  const double* rho;
+  const int32_t* idx_diff;
+  const int32_t* idx_sum;
+  const int8_t* sign;
+  const int32_t* cls;
+};
+
+// n(t+dt) for dn/dt = gain - loss n with frozen coefficients (solver.py:640-665)
+__device__ __forceinline__ double relax_update(double n, double gain, double loss, double dt) {
+  const double mu = fmax(loss, 0.0);
+  const double P = fmax(gain + (mu - loss) * n, 0.0);
+  const double decay = exp(-mu * dt);
+  const double coeff = (mu < 1e-14) ? dt : (1.0 - decay) / mu;
+  return fmax(decay * n + coeff * P, 0.0);
+}
+
+// y(t+dt) for y' = a + b y with frozen coefficients (solver.py:686-700)
+__device__ __forceinline__ double affine_update(double y, double a, double b, double dt) {
+  const double xx = fmin(fmax(b * dt, -80.0), 80.0);
+  const double ex = exp(xx);
+  const double coeff = (fabs(b) < 1e-14) ? dt : (ex - 1.0) / b;
+  return fmax(ex * y + coeff * a, 0.0);
+}
+
+__global__ void __launch_bounds__(256) collision_generic_kernel(CollView t, const uint8_t* __restrict__ flags,
+                                                                long ncell, const double* __restrict__ sin_,
+                                                                double* __restrict__ sout, double* __restrict__ ph,
+                                                                double* __restrict__ acc, double dE, double dt,
+                                                                int en_r, int en_s, int upd_ph) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= ncell) return;
+  const int NE = t.ne, NW = t.nw;
+  if (!(flags[p] & QP_FLAG_ACTIVE)) {
+    for (int i = 0; i < NE; ++i) sout[(long)i * ncell + p] = sin_[(long)i * ncell + p];
+    return;
+  }
+  const int c = t.cls ? t.cls[p] : 0;
+  const double* rho = t.rho + (long)c * NE;
+  const double* kr = t.kr0 ? t.kr0 + (long)c * NE * NE : nullptr;
+  const double* ks = t.ks0 ? t.ks0 + (long)c * NE * NE : nullptr;
+  const bool use_r = en_r && kr;
+  const bool use_s = en_s && ks;
+
+  // ---- quasiparticle update: gain / loss rates from the OLD n and p ----
+  for (int i = 0; i < NE; ++i) {
+    const double ni = sin_[(long)i * ncell + p];
+    const double rho_i = rho[i];
+    const double qi = rho_i * fmax(1.0 - ni / fmax(rho_i, 1e-30), 0.0);
+    double g_s = 0.0, l_s = 0.0, g_r = 0.0, l_r = 0.0;
+    for (int j = 0; j < NE; ++j) {
+      const double nj = sin_[(long)j * ncell + p];
+      const double rho_j = rho[j];
+      const double qj = rho_j * fmax(1.0 - nj / fmax(rho_j, 1e-30), 0.0);
+      if (use_s && j != i) {
+        const double pd = ph[(long)t.idx_diff[i * NE + j] * ncell + p];  // |Ei-Ej| bin, symmetric in (i,j)
+        const double np_ij = t.sign[i * NE + j] > 0 ? 1.0 + pd : pd;
+        const double np_ji = t.sign[j * NE + i] > 0 ? 1.0 + pd : pd;
+        g_s += ks[j * NE + i] * np_ji * nj;
+        l_s += ks[i * NE + j] * np_ij * qj;
+      }
+      if (use_r) {
+        const double ps = ph[(long)t.idx_sum[i * NE + j] * ncell + p];
+        const double k = kr[i * NE + j];
+        l_r += k * (1.0 + ps) * nj;
+        g_r += k * ps * qj;
+      }
+    }
+    const double gain = dE * qi * g_s + 2.0 * dE * qi * g_r;
+    const double loss = dE * l_s + 2.0 * dE * l_r;
+    sout[(long)i * ncell + p] = relax_update(ni, gain, loss, dt);
+  }
+  if (!upd_ph || !(en_r || en_s)) return;
+
+  // ---- phonon update: bin the pair rates (bincount of solver.py:758-788) ----
+  double* A = acc;
+  double* B = acc + (long)NW * ncell;
+  for (int w = 0; w < NW; ++w) {
+    A[(long)w * ncell + p] = 0.0;
+    B[(long)w * ncell + p] = 0.0;
+  }
+  for (int i = 0; i < NE; ++i) {
+    const double ni = sin_[(long)i * ncell + p];
+    const double rho_i = rho[i];
+    const double qi = rho_i * fmax(1.0 - ni / fmax(rho_i, 1e-30), 0.0);
+    for (int j = 0; j < NE; ++j) {
+      const double nj = sin_[(long)j * ncell + p];
+      const double rho_j = rho[j];
+      const double qj = rho_j * fmax(1.0 - nj / fmax(rho_j, 1e-30), 0.0);
+      if (use_s && j != i) {
+        const long w = (long)t.idx_diff[i * NE + j] * ncell + p;
+        const double base = dE * (ni * ks[i * NE + j] * qj);
+        const int sg = t.sign[i * NE + j];
+        if (sg > 0) {
+          A[w] += base;
+          B[w] += base;
+        } else if (sg < 0) {
+          B[w] -= base;
+        }
+      }
+      if (use_r) {
+        const long w = (long)t.idx_sum[i * NE + j] * ncell + p;
+        const double k = kr[i * NE + j];
+        const double rec = dE * (ni * k * nj);
+        const double pb = dE * (qi * k * qj);
+        A[w] += rec;
+        B[w] += rec - pb;
+      }
+    }
+  }
+  for (int w = 0; w < NW; ++w) {
+    const long o = (long)w * ncell + p;
+    ph[o] = affine_update(ph[o], A[o], B[o], dt);
+  }
+}
+
+}  // namespace qp
+
+extern "C" int qp_collision_step(const qp_collision_tables* t, const uint8_t* flags, int64_t ncell,
+                                 const double* state_in, double* state_out, double* phonon, double* ph_scratch,
+                                 double dE, double dt, int enable_recombination, int enable_scattering,
+                                 int update_phonons, void* stream) {
+  QP_REQUIRE(t != nullptr, "tables are NULL");
+  QP_REQUIRE(t->ne > 0 && t->nw > 0 && t->nclass > 0, "ne, nw, nclass must be positive");
+  QP_REQUIRE(t->rho && t->idx_diff && t->idx_sum && t->sign, "rho / idx maps / sign must be non-NULL");
+  QP_REQUIRE(t->nclass == 1 || t->cls, "cls is required when nclass > 1");
+  QP_REQUIRE(flags && state_in && state_out && phonon, "flags, state_in, state_out, phonon must be non-NULL");
+  QP_REQUIRE(state_in != state_out, "state_in and state_out must not alias");
+  QP_REQUIRE(ncell > 0, "ncell must be positive");
+  QP_REQUIRE(!(update_phonons && (enable_recombination || enable_scattering)) || ph_scratch,
+             "ph_scratch is required when phonons are updated");
+  qp::CollView v{t->ne, t->nw, t->nclass, t->kr0, t->ks0, t->rho, t->idx_diff, t->idx_sum, t->sign, t->cls};
+  const unsigned blocks = (unsigned)((ncell + 255) / 256);
+  hipLaunchKernelGGL(qp::collision_generic_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, flags,
+                     (long)ncell, state_in, state_out, phonon, ph_scratch, dE, dt, enable_recombination,
+                     enable_scattering, update_phonons);
+  return qp::check_launch("qp_collision_step");
+}

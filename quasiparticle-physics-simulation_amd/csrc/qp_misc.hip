@@ -1,0 +1,212 @@
+// Small elementwise / reduction kernels of the time loop: external generation, Pauli guard statistics,
+// energy integrals, max-norm.
+#include "qp_common.h"
+
+namespace qp {
+
+__global__ void __launch_bounds__(256) add_constant_kernel(const uint8_t* __restrict__ flags, long ncell,
+                                                           int nfield, double* __restrict__ s, double amount) {
+  const long total = ncell * nfield;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const long p = t % ncell;
+    if (flags[p] & QP_FLAG_ACTIVE) s[t] += amount;
+  }
+}
+
+__global__ void __launch_bounds__(256) add_scaled_kernel(long n, double* __restrict__ s,
+                                                         const double* __restrict__ g, double scale) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x)
+    s[t] += scale * g[t];
+}
+
+__global__ void __launch_bounds__(256) energy_integrate_kernel(const double* __restrict__ s, int ne, long ncell,
+                                                               double dE, double* __restrict__ out) {
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < ncell; p += (long)gridDim.x * blockDim.x) {
+    double acc = 0.0;
+    for (int i = 0; i < ne; ++i) acc += s[(long)i * ncell + p];
+    out[p] = acc * dE;
+  }
+}
+
+__global__ void __launch_bounds__(256) weighted_sum_kernel(const double* __restrict__ s,
+                                                           const double* __restrict__ w, int n, long ncell,
+                                                           double* __restrict__ out) {
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < ncell; p += (long)gridDim.x * blockDim.x) {
+    double acc = 0.0;
+    for (int i = 0; i < n; ++i) acc += s[(long)i * ncell + p] * w[i];
+    out[p] = acc;
+  }
+}
+
+// ---- reductions: per-block partials in workspace, finished by a single-block kernel -----------------------
+constexpr int kRedBlocks = 1024;
+
+struct PauliPartial {
+  double maxf;
+  long maxidx;
+  long forb;
+};
+
+__device__ __forceinline__ void pauli_merge(double& f, long& fi, long& forb, double of, long ofi, long oforb) {
+  if (of > f || (of == f && ofi < fi)) { f = of; fi = ofi; }
+  if (oforb >= 0 && (forb < 0 || oforb < forb)) forb = oforb;
+}
+
+__device__ void pauli_block_reduce(double f, long fi, long forb, PauliPartial* dst) {
+  __shared__ double sf[256];
+  __shared__ long si[256];
+  __shared__ long sb[256];
+  const int t = threadIdx.x;
+  sf[t] = f; si[t] = fi; sb[t] = forb;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) pauli_merge(sf[t], si[t], sb[t], sf[t + s], si[t + s], sb[t + s]);
+    __syncthreads();
+  }
+  if (t == 0) { dst->maxf = sf[0]; dst->maxidx = si[0]; dst->forb = sb[0]; }
+}
+
+__global__ void __launch_bounds__(256) pauli_partial_kernel(const double* __restrict__ s,
+                                                            const double* __restrict__ rho,
+                                                            const int32_t* __restrict__ cls,
+                                                            const uint8_t* __restrict__ flags, int ne, long ncell,
+                                                            double floor_, PauliPartial* part) {
+  // f defaults to 0 where rho <= 1e-30 (np.divide(..., where=rho_mask) into zeros, solver.py:987-992);
+  // np.argmax returns the first maximum in C order, so ties resolve to the smallest linear index.
+  double f = -1.0;
+  long fi = 0x7fffffffffffffffL, forb = -1;
+  const long total = ncell * ne;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const long p = t % ncell;
+    if (!(flags[p] & QP_FLAG_ACTIVE)) continue;
+    const int i = (int)(t / ncell);
+    const double r = rho[(long)(cls ? cls[p] : 0) * ne + i];
+    const double n = s[t];
+    double occ = 0.0;
+    if (r > 1e-30) occ = n / fmax(r, 1e-30);
+    else if (n > floor_ && (forb < 0 || t < forb)) forb = t;
+    if (occ > f || (occ == f && t < fi)) { f = occ; fi = t; }
+  }
+  pauli_block_reduce(f, fi, forb, part + blockIdx.x);
+}
+
+__global__ void __launch_bounds__(256) pauli_final_kernel(const PauliPartial* part, int nparts, double* out_vals,
+                                                          long* out_idx) {
+  double f = -1.0;
+  long fi = 0x7fffffffffffffffL, forb = -1;
+  for (int k = threadIdx.x; k < nparts; k += blockDim.x) pauli_merge(f, fi, forb, part[k].maxf, part[k].maxidx, part[k].forb);
+  __shared__ PauliPartial res;
+  pauli_block_reduce(f, fi, forb, &res);
+  __syncthreads();
+  if (threadIdx.x == 0) { out_vals[0] = res.maxf; out_idx[0] = res.maxidx; out_idx[1] = res.forb; }
+}
+
+__global__ void __launch_bounds__(256) absmax_partial_kernel(const double* __restrict__ a, long n, double* part) {
+  double m = 0.0;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+    const double v = fabs(a[t]);
+    // NaN must not be lost: propagate it as +inf so a diverged iteration is visible
+    m = (v != v) ? __builtin_huge_val() : fmax(m, v);
+  }
+  __shared__ double sm[256];
+  sm[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = sm[0];
+}
+
+__global__ void __launch_bounds__(256) absmax_final_kernel(const double* part, int nparts, double* out) {
+  double m = 0.0;
+  for (int k = threadIdx.x; k < nparts; k += blockDim.x) m = fmax(m, part[k]);
+  __shared__ double sm[256];
+  sm[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sm[0];
+}
+
+__global__ void __launch_bounds__(256) axpy_kernel(long n, double alpha, const double* __restrict__ x,
+                                                   double* __restrict__ y) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x)
+    y[t] += alpha * x[t];
+}
+
+static inline unsigned grid_for(long n) {
+  long b = (n + 255) / 256;
+  return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+}  // namespace qp
+
+extern "C" {
+
+int qp_add_constant(const uint8_t* flags, int64_t ncell, int32_t nfield, double* state, double amount, void* stream) {
+  QP_REQUIRE(flags && state && ncell > 0 && nfield > 0, "bad arguments");
+  hipLaunchKernelGGL(qp::add_constant_kernel, dim3(qp::grid_for(ncell * nfield)), dim3(256), 0, (hipStream_t)stream,
+                     flags, (long)ncell, (int)nfield, state, amount);
+  return qp::check_launch("qp_add_constant");
+}
+
+int qp_add_scaled(int64_t n, double* state, const double* g, double scale, void* stream) {
+  QP_REQUIRE(state && g && n > 0, "bad arguments");
+  hipLaunchKernelGGL(qp::add_scaled_kernel, dim3(qp::grid_for(n)), dim3(256), 0, (hipStream_t)stream, (long)n, state,
+                     g, scale);
+  return qp::check_launch("qp_add_scaled");
+}
+
+int64_t qp_pauli_workspace_bytes(void) { return (int64_t)qp::kRedBlocks * (int64_t)sizeof(qp::PauliPartial); }
+
+int qp_pauli_stats(const double* state, const double* rho, const int32_t* cls, const uint8_t* flags, int32_t ne,
+                   int32_t nclass, int64_t ncell, double density_floor, void* workspace, double* out_vals,
+                   int64_t* out_idx, void* stream) {
+  QP_REQUIRE(state && rho && flags && workspace && out_vals && out_idx, "NULL argument");
+  QP_REQUIRE(ne > 0 && nclass > 0 && ncell > 0, "ne, nclass, ncell must be positive");
+  QP_REQUIRE(nclass == 1 || cls, "cls is required when nclass > 1");
+  long blocks = (ncell * ne + 255) / 256;
+  if (blocks > qp::kRedBlocks) blocks = qp::kRedBlocks;
+  auto* part = (qp::PauliPartial*)workspace;
+  hipLaunchKernelGGL(qp::pauli_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, state, rho,
+                     cls, flags, (int)ne, (long)ncell, density_floor, part);
+  hipLaunchKernelGGL(qp::pauli_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, (int)blocks, out_vals,
+                     (long*)out_idx);
+  return qp::check_launch("qp_pauli_stats");
+}
+
+int qp_energy_integrate(const double* state, int32_t ne, int64_t ncell, double dE, double* out, void* stream) {
+  QP_REQUIRE(state && out && ne > 0 && ncell > 0, "bad arguments");
+  hipLaunchKernelGGL(qp::energy_integrate_kernel, dim3(qp::grid_for(ncell)), dim3(256), 0, (hipStream_t)stream, state,
+                     (int)ne, (long)ncell, dE, out);
+  return qp::check_launch("qp_energy_integrate");
+}
+
+int qp_weighted_sum(const double* state, const double* weights, int32_t n, int64_t ncell, double* out, void* stream) {
+  QP_REQUIRE(state && weights && out && n > 0 && ncell > 0, "bad arguments");
+  hipLaunchKernelGGL(qp::weighted_sum_kernel, dim3(qp::grid_for(ncell)), dim3(256), 0, (hipStream_t)stream, state,
+                     weights, (int)n, (long)ncell, out);
+  return qp::check_launch("qp_weighted_sum");
+}
+
+int qp_absmax(const double* a, int64_t n, void* workspace, double* out_val, void* stream) {
+  QP_REQUIRE(a && workspace && out_val && n > 0, "bad arguments");
+  long blocks = (n + 255) / 256;
+  if (blocks > qp::kRedBlocks) blocks = qp::kRedBlocks;
+  hipLaunchKernelGGL(qp::absmax_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, (long)n,
+                     (double*)workspace);
+  hipLaunchKernelGGL(qp::absmax_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace,
+                     (int)blocks, out_val);
+  return qp::check_launch("qp_absmax");
+}
+
+int qp_axpy(int64_t n, double alpha, const double* x, double* y, void* stream) {
+  QP_REQUIRE(x && y && n > 0, "bad arguments");
+  hipLaunchKernelGGL(qp::axpy_kernel, dim3(qp::grid_for(n)), dim3(256), 0, (hipStream_t)stream, (long)n, alpha, x, y);
+  return qp::check_launch("qp_axpy");
+}
+
+}  // extern "C"

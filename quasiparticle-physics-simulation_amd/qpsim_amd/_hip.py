@@ -1,0 +1,94 @@
+"""ctypes binding of ``libqpsim_hip.so`` (C ABI declared in ``include/qpsim_hip.h``).
+
+There is no CPU fallback: if the shared library is missing or no HIP device is visible the
+first compute call raises ``RuntimeError`` -- build with ``python __graft_entry__.py`` or
+``make -C quasiparticle-physics-simulation_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+LIB_NAME = "libqpsim_hip.so"
+_LIB_PATH = Path(__file__).resolve().parent / LIB_NAME
+_lib = None
+
+c_dp = C.c_void_p  # device pointers travel as raw addresses
+
+
+class GridDesc(C.Structure):
+    """Mirror of ``qp_grid_desc``."""
+    _fields_ = [("ny", C.c_int32), ("nx", C.c_int32), ("nfield", C.c_int32),
+                ("flags", c_dp), ("ex", c_dp), ("ey", c_dp), ("sx", c_dp), ("sy", c_dp),
+                ("dcoef", c_dp), ("dfield", c_dp)]
+
+
+class CollisionTables(C.Structure):
+    """Mirror of ``qp_collision_tables``."""
+    _fields_ = [("ne", C.c_int32), ("nw", C.c_int32), ("nclass", C.c_int32),
+                ("kr0", c_dp), ("ks0", c_dp), ("rho", c_dp), ("idx_diff", c_dp), ("idx_sum", c_dp),
+                ("sign", c_dp), ("cls", c_dp)]
+
+
+class RectPlan(C.Structure):
+    """Opaque ``qp_adi_rect_plan``; only ever handled by pointer."""
+
+
+# name -> (restype, argtypes); must list every symbol declared in include/qpsim_hip.h
+SIGNATURES = {
+    "qp_version": (C.c_int, []),
+    "qp_last_error": (C.c_char_p, []),
+    "qp_stencil_combine": (C.c_int, [C.POINTER(GridDesc), C.c_double, c_dp, c_dp, c_dp, C.c_double, C.c_double,
+                                     C.c_double, C.c_double, C.c_double, c_dp]),
+    "qp_implicit_sweep": (C.c_int, [C.POINTER(GridDesc), C.c_double, C.c_int, c_dp, c_dp, c_dp, c_dp]),
+    "qp_collision_step": (C.c_int, [C.POINTER(CollisionTables), c_dp, C.c_int64, c_dp, c_dp, c_dp, c_dp,
+                                    C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, c_dp]),
+    "qp_add_constant": (C.c_int, [c_dp, C.c_int64, C.c_int32, c_dp, C.c_double, c_dp]),
+    "qp_add_scaled": (C.c_int, [C.c_int64, c_dp, c_dp, C.c_double, c_dp]),
+    "qp_pauli_workspace_bytes": (C.c_int64, []),
+    "qp_pauli_stats": (C.c_int, [c_dp, c_dp, c_dp, c_dp, C.c_int32, C.c_int32, C.c_int64, C.c_double, c_dp, c_dp,
+                                 c_dp, c_dp]),
+    "qp_energy_integrate": (C.c_int, [c_dp, C.c_int32, C.c_int64, C.c_double, c_dp, c_dp]),
+    "qp_weighted_sum": (C.c_int, [c_dp, c_dp, C.c_int32, C.c_int64, c_dp, c_dp]),
+    "qp_absmax": (C.c_int, [c_dp, C.c_int64, c_dp, c_dp, c_dp]),
+    "qp_axpy": (C.c_int, [C.c_int64, C.c_double, c_dp, c_dp, c_dp]),
+}
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def library_path() -> Path:
+    return Path(os.environ.get("QPSIM_HIP_LIBRARY", _LIB_PATH))
+
+
+def load():
+    """Load the shared library and attach signatures (idempotent)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not path.exists():
+        raise HipLibraryMissing(
+            f"{path} not found: the HIP extension is not built. Run `python __graft_entry__.py` "
+            "(or `make -C quasiparticle-physics-simulation_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(str(path))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class QPHipError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().qp_last_error()
+        raise QPHipError(f"{what or 'libqpsim_hip call'} failed with status {rc}: "
+                         f"{msg.decode(errors='replace') if msg else ''}")

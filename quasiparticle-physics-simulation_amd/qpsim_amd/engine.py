@@ -1,0 +1,334 @@
+"""Device-side engine: geometry compilation, resident state and kernel sequencing.
+
+Host code here is plumbing only (PyTorch-ROCm tensors for device memory and streams, ctypes calls
+into ``libqpsim_hip.so``).  All arithmetic of the time loop runs in the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _hip
+from .models import BoundaryCondition, EdgeSegment
+
+FLAG_XM, FLAG_XP, FLAG_YM, FLAG_YP, FLAG_ACTIVE = 1, 2, 4, 8, 16
+_DIRECTIONS = ("up", "down", "left", "right")  # the reference's face walk order (solver.py:25-30)
+
+
+class BoundaryAssignmentError(ValueError):
+    """A boundary face or edge has no boundary condition (reference solver.py:21)."""
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def require_gpu():
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise RuntimeError("qpsim_amd needs a HIP device (torch.cuda.is_available() is False); "
+                           "there is no CPU fallback for the time loop.")
+    return torch
+
+
+# --------------------------------------------------------------------------------------------------------- #
+# geometry compilation (host, vectorised): mask + edges + edge_conditions -> per-cell operator tables
+# --------------------------------------------------------------------------------------------------------- #
+@dataclass
+class CompiledGeometry:
+    mask: np.ndarray      # [ny, nx] bool
+    dx: float
+    flags: np.ndarray     # [ny, nx] uint8
+    ex: np.ndarray        # [ny, nx] f64, BC diagonal terms of x-faces in 1/dx^2 units
+    ey: np.ndarray
+    sx: np.ndarray        # BC sources in 1/dx^2 units
+    sy: np.ndarray
+
+    @property
+    def is_full_rectangle(self) -> bool:
+        return bool(self.mask.all())
+
+
+def _face_terms(bc: BoundaryCondition, dx: float) -> tuple[float, float]:
+    """(diagonal, source) contribution of one boundary face in units of 1/dx^2 (solver.py:112-149)."""
+    kind = bc.normalized_kind()
+    if kind == "reflective":
+        return 0.0, 0.0
+    if kind == "absorbing":
+        return 2.0, 0.0
+    if kind == "dirichlet":
+        return 2.0, 2.0 * float(bc.value or 0.0)
+    if kind == "neumann":
+        return 0.0, float(bc.value or 0.0) * dx
+    if kind == "robin":
+        return float(bc.value or 0.0) * dx, float(bc.aux_value or 0.0) * dx
+    raise BoundaryAssignmentError(f"Unsupported boundary kind: {bc.kind}")
+
+
+def link_flags(mask: np.ndarray) -> np.ndarray:
+    m = np.asarray(mask, dtype=bool)
+    pad = np.zeros((m.shape[0] + 2, m.shape[1] + 2), dtype=bool)
+    pad[1:-1, 1:-1] = m
+    f = np.zeros(m.shape, dtype=np.uint8)
+    f |= (m & pad[1:-1, :-2]).astype(np.uint8) * FLAG_XM
+    f |= (m & pad[1:-1, 2:]).astype(np.uint8) * FLAG_XP
+    f |= (m & pad[:-2, 1:-1]).astype(np.uint8) * FLAG_YM
+    f |= (m & pad[2:, 1:-1]).astype(np.uint8) * FLAG_YP
+    f |= m.astype(np.uint8) * FLAG_ACTIVE
+    return f
+
+
+def compile_geometry(mask: np.ndarray, edges: list[EdgeSegment], edge_conditions: dict[str, BoundaryCondition],
+                     dx: float) -> CompiledGeometry:
+    """Per-cell link flags and boundary terms; same checks / errors as solver.py:152-212."""
+    if dx <= 0:
+        raise ValueError("dx must be positive.")
+    mask = np.asarray(mask, dtype=bool)
+    if mask.ndim != 2:
+        raise ValueError("mask must be 2D.")
+    if not mask.any():
+        raise ValueError("Geometry mask has no interior points.")
+    ny, nx = mask.shape
+    # BC index per face; later edges overwrite earlier ones, edges without a BC are skipped (solver.py:37-50)
+    bc_list: list[tuple[float, float]] = []
+    face_bc = {d: np.full((ny, nx), -1, dtype=np.int32) for d in _DIRECTIONS}
+    for edge in edges:
+        bc = edge_conditions.get(edge.edge_id)
+        if bc is None:
+            continue
+        bc.validate()
+        bc_list.append(_face_terms(bc, dx))
+        k = len(bc_list) - 1
+        for d in _DIRECTIONS:
+            rc = [(f.row, f.col) for f in edge.faces if f.direction == d]
+            if rc:
+                rows, cols = np.asarray(rc, dtype=np.int64).T
+                face_bc[d][rows, cols] = k
+    missing = [e.edge_id for e in edges if e.edge_id not in edge_conditions]
+    if missing:
+        raise BoundaryAssignmentError(
+            f"All edges must be assigned boundary conditions before simulation. Missing: {len(missing)}")
+
+    flags = link_flags(mask)
+    link_of = {"up": FLAG_YM, "down": FLAG_YP, "left": FLAG_XM, "right": FLAG_XP}
+    diag = np.asarray([t[0] for t in bc_list] + [0.0])
+    src = np.asarray([t[1] for t in bc_list] + [0.0])
+    ex = np.zeros((ny, nx))
+    ey = np.zeros((ny, nx))
+    sx = np.zeros((ny, nx))
+    sy = np.zeros((ny, nx))
+    unassigned = np.zeros((ny, nx), dtype=np.int8)  # 1 + index of first direction lacking a BC
+    for order, d in reversed(list(enumerate(_DIRECTIONS))):
+        boundary = mask & ((flags & link_of[d]) == 0)
+        k = face_bc[d]
+        bad = boundary & (k < 0)
+        unassigned[bad] = order + 1
+        kk = np.where(boundary & (k >= 0), k, len(bc_list))
+        if d in ("left", "right"):
+            ex += diag[kk]
+            sx += src[kk]
+        else:
+            ey += diag[kk]
+            sy += src[kk]
+    if unassigned.any():
+        r, c = (int(v) for v in np.argwhere(unassigned > 0)[0])
+        d = _DIRECTIONS[int(unassigned[r, c]) - 1]
+        raise BoundaryAssignmentError(f"Missing boundary condition for face at cell ({r}, {c}) direction '{d}'.")
+    return CompiledGeometry(mask, float(dx), flags, ex, ey, sx, sy)
+
+
+# --------------------------------------------------------------------------------------------------------- #
+# device engine
+# --------------------------------------------------------------------------------------------------------- #
+def _ptr(t) -> int:
+    return 0 if t is None else int(t.data_ptr())
+
+
+class DiffusionOperator:
+    """(I - r L_x), (I - r L_y) and friends for one time step size on a batch of fields."""
+
+    def __init__(self, engine: "Engine", nfield: int, dt: float, dcoef=None, dfield=None):
+        torch = engine.torch
+        self.engine = engine
+        self.nfield = int(nfield)
+        self.dt = float(dt)
+        self.r = 0.5 * self.dt / (engine.geom.dx * engine.geom.dx)
+        self.dcoef = None if dcoef is None else torch.as_tensor(np.asarray(dcoef, dtype=np.float64), device=engine.device)
+        self.dfield = None if dfield is None else torch.as_tensor(
+            np.ascontiguousarray(dfield, dtype=np.float64), device=engine.device)
+        if (self.dcoef is None) == (self.dfield is None):
+            raise ValueError("give exactly one of dcoef / dfield")
+        g = engine
+        self.desc = _hip.GridDesc(g.ny, g.nx, self.nfield, _ptr(g.d_flags), _ptr(g.d_ex), _ptr(g.d_ey), _ptr(g.d_sx),
+                                  _ptr(g.d_sy), _ptr(self.dcoef), _ptr(self.dfield))
+
+
+class Engine:
+    """Owns the device copies of one geometry and sequences the kernels on torch's current stream."""
+
+    def __init__(self, geom: CompiledGeometry, device: str | int | None = None):
+        torch = require_gpu()
+        self.torch = torch
+        self.lib = _hip.load()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.geom = geom
+        self.ny, self.nx = geom.mask.shape
+        self.ncell = self.ny * self.nx
+        up = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=self.device)  # noqa: E731
+        self.d_flags = up(geom.flags, np.uint8)
+        self.d_ex, self.d_ey = up(geom.ex, np.float64), up(geom.ey, np.float64)
+        self.d_sx, self.d_sy = up(geom.sx, np.float64), up(geom.sy, np.float64)
+        self.mask_flat = geom.mask.reshape(-1)
+        self._ws = torch.empty(int(self.lib.qp_pauli_workspace_bytes()), dtype=torch.uint8, device=self.device)
+        self._red_vals = torch.zeros(2, dtype=torch.float64, device=self.device)
+        self._red_idx = torch.zeros(2, dtype=torch.int64, device=self.device)
+        self._scratch = {}
+
+    # -- plumbing -------------------------------------------------------------------------------------------
+    @property
+    def stream(self) -> int:
+        return int(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def empty(self, *shape):
+        return self.torch.empty(*shape, dtype=self.torch.float64, device=self.device)
+
+    def scratch(self, key: str, numel: int):
+        buf = self._scratch.get(key)
+        if buf is None or buf.numel() < numel:
+            buf = self.empty(int(numel))
+            self._scratch[key] = buf
+        return buf
+
+    def upload_packed(self, packed: np.ndarray):
+        """[nfield, n_interior] host array (reference layout) -> [nfield, ncell] device planes, holes = 0."""
+        packed = np.asarray(packed, dtype=np.float64)
+        full = np.zeros((packed.shape[0], self.ncell), dtype=np.float64)
+        full[:, self.mask_flat] = packed
+        return self.torch.as_tensor(full, device=self.device)
+
+    def download_packed(self, planes) -> np.ndarray:
+        return planes.detach().cpu().numpy()[:, self.mask_flat]
+
+    # -- diffusion --------------------------------------------------------------------------------------------
+    def stencil(self, op: DiffusionOperator, u, out, c0, cx, cy, cs, rin=None, cr=0.0):
+        _hip.check(self.lib.qp_stencil_combine(C.byref(op.desc), op.r, _ptr(u), _ptr(rin), _ptr(out), c0, cx, cy, cs,
+                                               cr, self.stream), "qp_stencil_combine")
+
+    def sweep(self, op: DiffusionOperator, direction: int, rhs, x):
+        scr = self.scratch("thomas", 2 * op.nfield * self.ncell)
+        _hip.check(self.lib.qp_implicit_sweep(C.byref(op.desc), op.r, direction, _ptr(rhs), _ptr(x), _ptr(scr),
+                                              self.stream), "qp_implicit_sweep")
+
+    def adi_step(self, op: DiffusionOperator, u, out=None):
+        """Peaceman-Rachford step: (I-rLx)u* = (I+rLy)u + rS; (I-rLy)u' = (I+rLx)u* + rS.  Returns u' (new tensor or `out`)."""
+        n = op.nfield * self.ncell
+        t1 = self.scratch("adi_t1", n).view(op.nfield, self.ncell)
+        t2 = self.scratch("adi_t2", n).view(op.nfield, self.ncell)
+        self.stencil(op, u, t1, 1.0, 0.0, 1.0, 1.0)
+        self.sweep(op, 0, t1, t1)
+        self.stencil(op, t1, t2, 1.0, 1.0, 0.0, 1.0)
+        res = u if out is None else out
+        self.sweep(op, 1, t2, res)
+        return res
+
+    def cn_exact_step(self, op: DiffusionOperator, u, rtol: float = 1e-13, max_iter: int = 400):
+        """Unsplit CN step (I - rL)u' = (I + rL)u + 2rS by ADI-preconditioned Richardson iteration, in place.
+
+        The ADI factorisation M = (I-rLx)(I-rLy) differs from A = I - rL by r^2 Lx Ly, so
+        v <- v + M^-1 (R - A v) contracts with factor rho(Tx Ty) < 1 (Tx = (I-rLx)^-1 rLx).  The starting
+        guess is the ADI step itself; on strips it is already exact and no iteration runs.
+        Returns the number of correction iterations.
+        """
+        n = op.nfield * self.ncell
+        R = self.scratch("cn_R", n).view(op.nfield, self.ncell)
+        res = self.scratch("cn_res", n).view(op.nfield, self.ncell)
+        v = self.scratch("cn_v", n).view(op.nfield, self.ncell)
+        self.stencil(op, u, R, 1.0, 1.0, 1.0, 2.0)
+        scale = self.absmax(R)
+        v.copy_(u)
+        self.adi_step(op, v)
+        its = 0
+        if scale == 0.0:
+            u.copy_(v)
+            return 0
+        while True:
+            self.stencil(op, v, res, -1.0, 1.0, 1.0, 0.0, rin=R, cr=1.0)
+            err = self.absmax(res)
+            if not np.isfinite(err):
+                raise FloatingPointError("exact-CN iteration diverged (non-finite residual)")
+            if err <= rtol * scale or its >= max_iter:
+                break
+            self.sweep(op, 0, res, res)
+            self.sweep(op, 1, res, res)
+            _hip.check(self.lib.qp_axpy(n, 1.0, _ptr(res), _ptr(v), self.stream), "qp_axpy")
+            its += 1
+        u.copy_(v)
+        return its
+
+    def absmax(self, a) -> float:
+        _hip.check(self.lib.qp_absmax(_ptr(a), a.numel(), _ptr(self._ws), _ptr(self._red_vals), self.stream), "qp_absmax")
+        return float(self._red_vals[0].item())
+
+    # -- collisions, generation, reductions -------------------------------------------------------------------
+    def make_collision_tables(self, kr0, ks0, rho, idx_diff, idx_sum, sign, cls_packed=None):
+        """Upload per-gap-class tables ([C,NE,NE], [C,NE]) and maps; returns an opaque handle."""
+        torch = self.torch
+        up = lambda a, dt: None if a is None else torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=self.device)  # noqa: E731
+        rho = np.atleast_2d(np.asarray(rho, dtype=np.float64))
+        nclass, ne = rho.shape
+        h = {"kr0": up(None if kr0 is None else np.asarray(kr0).reshape(nclass, ne, ne), np.float64),
+             "ks0": up(None if ks0 is None else np.asarray(ks0).reshape(nclass, ne, ne), np.float64),
+             "rho": up(rho, np.float64), "idx_diff": up(idx_diff, np.int32), "idx_sum": up(idx_sum, np.int32),
+             "sign": up(sign, np.int8), "cls": None, "ne": ne, "nclass": nclass}
+        nw = int(max(np.max(idx_diff), np.max(idx_sum))) + 1
+        if nclass > 1:
+            if cls_packed is None:
+                raise ValueError("cls is required for more than one gap class")
+            full = np.zeros(self.ncell, dtype=np.int32)
+            full[self.mask_flat] = np.asarray(cls_packed, dtype=np.int32)
+            h["cls"] = up(full, np.int32)
+        h["nw"] = nw
+        h["struct"] = _hip.CollisionTables(ne, nw, nclass, _ptr(h["kr0"]), _ptr(h["ks0"]), _ptr(h["rho"]),
+                                           _ptr(h["idx_diff"]), _ptr(h["idx_sum"]), _ptr(h["sign"]), _ptr(h["cls"]))
+        return h
+
+    def collide(self, tables, state, state_out, phonon, dE, dt, en_r, en_s, update_phonons):
+        acc = self.scratch("coll_acc", 2 * tables["nw"] * self.ncell) if (update_phonons and (en_r or en_s)) else None
+        _hip.check(self.lib.qp_collision_step(C.byref(tables["struct"]), _ptr(self.d_flags), self.ncell, _ptr(state),
+                                              _ptr(state_out), _ptr(phonon), _ptr(acc), float(dE), float(dt),
+                                              int(bool(en_r)), int(bool(en_s)), int(bool(update_phonons)), self.stream),
+                   "qp_collision_step")
+
+    def add_constant(self, state, amount: float):
+        _hip.check(self.lib.qp_add_constant(_ptr(self.d_flags), self.ncell, state.shape[0], _ptr(state), float(amount),
+                                            self.stream), "qp_add_constant")
+
+    def add_scaled(self, state, g, scale: float):
+        _hip.check(self.lib.qp_add_scaled(state.numel(), _ptr(state), _ptr(g), float(scale), self.stream), "qp_add_scaled")
+
+    def pauli_stats(self, state, tables, floor: float):
+        """(max occupation, (energy index, cell index), forbidden (energy, cell) or None)."""
+        _hip.check(self.lib.qp_pauli_stats(_ptr(state), _ptr(tables["rho"]), _ptr(tables["cls"]), _ptr(self.d_flags),
+                                           tables["ne"], tables["nclass"], self.ncell, float(floor), _ptr(self._ws),
+                                           _ptr(self._red_vals), _ptr(self._red_idx), self.stream), "qp_pauli_stats")
+        mx = float(self._red_vals[0].item())
+        idx = self._red_idx.cpu().numpy()
+        top = (int(idx[0] // self.ncell), int(idx[0] % self.ncell))
+        forb = None if idx[1] < 0 else (int(idx[1] // self.ncell), int(idx[1] % self.ncell))
+        return mx, top, forb
+
+    def energy_integral(self, state, dE: float):
+        out = self.empty(self.ncell)
+        _hip.check(self.lib.qp_energy_integrate(_ptr(state), state.shape[0], self.ncell, float(dE), _ptr(out),
+                                                self.stream), "qp_energy_integrate")
+        return out
+
+    def weighted_sum(self, planes, weights):
+        out = self.empty(self.ncell)
+        w = self.torch.as_tensor(np.asarray(weights, dtype=np.float64), device=self.device)
+        _hip.check(self.lib.qp_weighted_sum(_ptr(planes), _ptr(w), planes.shape[0], self.ncell, _ptr(out), self.stream),
+                   "qp_weighted_sum")
+        return out

@@ -1,0 +1,317 @@
+"""GPU parity tests: every call goes through the C ABI of libqpsim_hip.so and is checked against the
+reference's golden vectors and the CPU oracle on the same inputs."""
+from __future__ import annotations
+
+import json
+import warnings
+
+import numpy as np
+import pytest
+
+from golden_utils import GOLDEN, GoldenRun, bcs_from_json, edges_from_json, oracle_kwargs, rel_err, run_names
+
+pytestmark = pytest.mark.gpu
+
+STRIP_TOL = 1e-10   # north_star: parity <= 1e-10 rel on the MKID cross-check (strip) configuration
+GRID_TOL = 1e-9     # 2-D grids, exact-CN mode iterated to 1e-13 residual
+ADI_TOL = 1e-11     # HIP ADI vs the oracle's ADI restatement (same algorithm, fp64 rounding only)
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import qp_oracle
+    return qp_oracle
+
+
+def _random_problem(seed, ny, nx, holes=True):
+    from qpsim_amd.geometry import extract_edge_segments
+    from qpsim_amd.models import BoundaryCondition
+    rng = np.random.default_rng(seed)
+    mask = np.ones((ny, nx), dtype=bool)
+    if holes:
+        mask &= rng.random((ny, nx)) > 0.15
+        mask[ny // 2, :] |= True
+    edges = extract_edge_segments(mask)
+    kinds = [BoundaryCondition("reflective"), BoundaryCondition("dirichlet", 0.4), BoundaryCondition("absorbing"),
+             BoundaryCondition("neumann", -0.05), BoundaryCondition("robin", 0.5, 0.1)]
+    bcs = {e.edge_id: kinds[int(rng.integers(0, 5))] for e in edges}
+    return rng, mask, edges, bcs
+
+
+@pytest.mark.parametrize("variable_d", [False, True])
+def test_stencil_and_sweeps_match_oracle(O, variable_d):
+    from qpsim_amd.engine import DiffusionOperator, Engine, compile_geometry
+    rng, mask, edges, bcs = _random_problem(3, 23, 37)
+    dx, dt, B = 0.7, 0.13, 3
+    geom = compile_geometry(mask, edges, bcs, dx)
+    eng = Engine(geom)
+    ops = O.build_grid_ops(mask, edges, bcs, dx)
+    n = int(mask.sum())
+    u = rng.random((B, n))
+    if variable_d:
+        Dp = 1.0 + 5.0 * rng.random((B, n))
+        dfull = np.zeros((B, mask.size))
+        dfull[:, mask.reshape(-1)] = Dp
+        op = DiffusionOperator(eng, B, dt, dfield=dfull)
+    else:
+        Dc = [2.0, 6.0, 0.0]
+        op = DiffusionOperator(eng, B, dt, dcoef=Dc)
+    d_u = eng.upload_packed(u)
+    for b in range(B):
+        Dg = np.zeros(mask.shape)
+        Dg[mask] = Dp[b] if variable_d else Dc[b]
+        st = O.ADIStepper(ops, Dg if variable_d else Dc[b], dt)
+        ug = np.zeros(mask.shape)
+        ug[mask] = u[b]
+        # explicit halves + source
+        out = eng.empty(B, eng.ncell)
+        eng.stencil(op, d_u, out, 1.0, 0.0, 1.0, 1.0)
+        want = st._explicit(ug, "y") + st.src
+        assert rel_err(eng.download_packed(out)[b], want[mask]) < 1e-14
+        eng.stencil(op, d_u, out, 1.0, 1.0, 0.0, 1.0)
+        want = st._explicit(ug, "x") + st.src
+        assert rel_err(eng.download_packed(out)[b], want[mask]) < 1e-14
+        # implicit sweeps
+        x = eng.empty(B, eng.ncell)
+        eng.sweep(op, 0, d_u, x)
+        want = O.thomas_batched(*st.ax, ug)
+        assert rel_err(eng.download_packed(x)[b], want[mask]) < 1e-13
+        eng.sweep(op, 1, d_u, x)
+        a, bb, c = (np.swapaxes(t, -1, -2) for t in st.ay)
+        want = np.swapaxes(O.thomas_batched(a, bb, c, ug.T), -1, -2)
+        assert rel_err(eng.download_packed(x)[b], want[mask]) < 1e-13
+        # full ADI step and exact CN step
+        v = d_u.clone()
+        eng.adi_step(op, v)
+        assert rel_err(eng.download_packed(v)[b], st.step(u[b])) < 1e-13
+        v = d_u.clone()
+        eng.cn_exact_step(op, v)
+        assert rel_err(eng.download_packed(v)[b], O.CNStepper(ops, Dg if variable_d else Dc[b], dt).step(u[b])) < 1e-11
+    assert np.all(eng.download_packed(v) == eng.download_packed(v))  # no NaN
+    full = v.cpu().numpy()
+    assert np.all(full[:, ~mask.reshape(-1)] == 0.0), "cells outside the mask must stay zero"
+
+
+def test_collision_kernel_matches_reference_vectors():
+    from qpsim_amd import tables as T
+    from qpsim_amd.solver import (apply_collision_step_fischer_catelani_nonuniform,
+                                  apply_collision_step_fischer_catelani_uniform)
+    z = np.load(GOLDEN / "collision_vectors.npz", allow_pickle=False)
+    meta = json.loads(str(z["meta_json"]))
+    worst = 0.0
+    for tag, m in meta.items():
+        if tag == "nonuni":
+            continue
+        E, dE = T.build_energy_grid(m["gap"], 1.0, m["fmax"], m["ne"])
+        om, idx_d, idx_s, sg = T.build_phonon_frequency_map(E)
+        s, p = z[f"{tag}_state_in"].copy(), z[f"{tag}_ph_in"].copy()
+        apply_collision_step_fischer_catelani_uniform(
+            s, p, T.recombination_kernel_base(E, m["gap"], m["tau_r"], m["T_c"]) if m["en_r"] else None,
+            T.scattering_kernel_base(E, m["gap"], m["tau_s"], m["T_c"]) if m["en_s"] else None,
+            T.dynes_density_of_states(E, m["gap"], m["gamma"]), idx_d, idx_s, sg, dE, m["dt"],
+            enable_recombination=m["en_r"], enable_scattering=m["en_s"])
+        worst = max(worst, rel_err(s, z[f"{tag}_state_out"]), rel_err(p, z[f"{tag}_ph_out"]))
+    assert worst < 1e-12, worst
+    m = meta["nonuni"]
+    E, dE = T.build_energy_grid(m["gap"], 1.0, m["fmax"], m["ne"])
+    om, idx_d, idx_s, sg = T.build_phonon_frequency_map(E)
+    gaps = z["nonuni_gaps"]
+    s, p = z["nonuni_state_in"].copy(), z["nonuni_ph_in"].copy()
+    apply_collision_step_fischer_catelani_nonuniform(
+        s, p, np.stack([T.recombination_kernel_base(E, g, m["tau_r"], m["T_c"]) for g in gaps]),
+        np.stack([T.scattering_kernel_base(E, g, m["tau_s"], m["T_c"]) for g in gaps]),
+        np.stack([T.dynes_density_of_states(E, g, m["gamma"]) for g in gaps]), idx_d, idx_s, sg, dE, m["dt"],
+        enable_recombination=True, enable_scattering=True)
+    assert rel_err(s, z["nonuni_state_out"]) < 1e-12 and rel_err(p, z["nonuni_ph_out"]) < 1e-12
+    # frozen phonons: quasiparticles move, phonons do not
+    tag = "c000"
+    m = meta[tag]
+    E, dE = T.build_energy_grid(m["gap"], 1.0, m["fmax"], m["ne"])
+    om, idx_d, idx_s, sg = T.build_phonon_frequency_map(E)
+    s, p = z[f"{tag}_state_in"].copy(), z[f"{tag}_ph_in"].copy()
+    apply_collision_step_fischer_catelani_uniform(
+        s, p, T.recombination_kernel_base(E, m["gap"], m["tau_r"], m["T_c"]),
+        T.scattering_kernel_base(E, m["gap"], m["tau_s"], m["T_c"]), T.dynes_density_of_states(E, m["gap"], m["gamma"]),
+        idx_d, idx_s, sg, dE, m["dt"], enable_recombination=True, enable_scattering=True, update_phonons=False)
+    assert rel_err(s, z[f"{tag}_state_out"]) < 1e-12 and np.array_equal(p, z[f"{tag}_ph_in"])
+
+
+def _compare_run(run: GoldenRun, res, ph, tol):
+    times, frames, mass, clim, eframes, E = res
+    sel = slice(-1, None) if run.final_only else slice(None)
+    assert np.allclose(times, run.expected("times"), rtol=0, atol=1e-12)
+    assert rel_err(np.stack(frames)[sel], run.expected("frames")) < tol
+    dx = float(run.kwargs["dx"])
+    scale = max(float(np.sum(np.abs(run.kwargs["initial_field"][run.kwargs["mask"]]))) * dx * dx,
+                float(np.max(np.abs(run.expected("mass")))))
+    assert np.max(np.abs(np.asarray(mass) - run.expected("mass"))) <= tol * scale
+    cscale = float(np.max(np.abs(run.expected("color_limits"))))
+    assert np.max(np.abs(np.asarray(clim) - run.expected("color_limits"))) <= tol * cscale
+    if run.expected("energy_frames") is not None:
+        got = np.stack([np.stack(ts) for ts in eframes])[sel]
+        assert rel_err(got, run.expected("energy_frames")) < tol
+        assert np.array_equal(E, run.expected("E_bins"))
+    else:
+        assert eframes is None and E is None
+    if run.want_phonon_history:
+        assert rel_err(np.stack(ph["phonon_frames"])[sel], run.expected("phonon_frames")) < tol
+        if run.expected("phonon_energy_frames") is not None:
+            got = np.stack([np.stack(ts) for ts in ph["phonon_energy_frames"]])[sel]
+            assert rel_err(got, run.expected("phonon_energy_frames")) < tol
+            assert np.array_equal(ph["phonon_energy_bins"], run.expected("phonon_energy_bins"))
+        else:
+            assert ph["phonon_energy_frames"] is None
+        assert ph["phonon_metadata"] == run.meta["phonon_metadata"]
+
+
+@pytest.mark.parametrize("name", run_names())
+def test_default_run_reproduces_reference(name):
+    """Drop-in call (default exact-CN scheme) against the recorded reference outputs."""
+    from qpsim_amd.solver import run_2d_crank_nicolson
+    run = GoldenRun(name)
+    kw = dict(run.kwargs)
+    ph = {} if run.want_phonon_history else None
+    if ph is not None:
+        kw["phonon_history_out"] = ph
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = run_2d_crank_nicolson(**kw)
+    _compare_run(run, res, ph, GRID_TOL if run.is_2d else STRIP_TOL)
+
+
+@pytest.mark.parametrize("name", [n for n in run_names() if GoldenRun(n).is_2d])
+def test_adi_scheme_matches_oracle_adi_on_2d(O, name):
+    """The benchmarked ADI kernel sequence vs the oracle's ADI restatement on the same 2-D inputs."""
+    from qpsim_amd.solver import run_2d_crank_nicolson
+    run = GoldenRun(name)
+    kw = dict(run.kwargs)
+    ph = {} if run.want_phonon_history else None
+    if ph is not None:
+        kw["phonon_history_out"] = ph
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = run_2d_crank_nicolson(**kw, diffusion_scheme="adi")
+        ref = O.run(**oracle_kwargs(run, "adi"))
+    assert rel_err(np.stack(got[1]), np.stack(ref[1])) < ADI_TOL
+    if got[4] is not None:
+        assert rel_err(np.stack([np.stack(t) for t in got[4]]), np.stack([np.stack(t) for t in ref[4]])) < ADI_TOL
+    if ph is not None and ph["phonon_energy_frames"] is not None:
+        assert rel_err(np.stack([np.stack(t) for t in ph["phonon_energy_frames"]]),
+                       np.stack([np.stack(t) for t in ref[6]["phonon_energy_frames"]])) < ADI_TOL
+
+
+def test_mkid_crosscheck_bound_of_the_reference_test():
+    """tests/test_mkid_crosscheck.py:194-207: rel < 1e-6 against the MKID-style 1-D update."""
+    from qpsim_amd.solver import run_2d_crank_nicolson
+    run = GoldenRun("xcheck_mkid_1x48_ne12")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = run_2d_crank_nicolson(**run.kwargs)
+    state = np.stack([np.stack(t) for t in res[4]])[:, :, 0, :]
+    ref1d = np.asarray(run.meta["extra"]["mkid_like_reference_1d"])
+    assert np.max(np.abs(state - ref1d)) / np.max(np.abs(ref1d)) < 1e-6
+    dE = float(res[5][1] - res[5][0])
+    assert np.max(np.abs(state.sum(1) * dE - ref1d.sum(1) * dE)) / np.max(np.abs(ref1d.sum(1) * dE)) < 1e-6
+
+
+def _one_pixel():
+    from qpsim_amd.geometry import extract_edge_segments
+    from qpsim_amd.models import BoundaryCondition
+    mask = np.ones((1, 1), dtype=bool)
+    edges = extract_edge_segments(mask)
+    return mask, edges, {e.edge_id: BoundaryCondition("reflective") for e in edges}
+
+
+def test_pauli_violation_raises_or_warns_like_the_reference():
+    """tests/test_physics_safety.py:57-106."""
+    from qpsim_amd.solver import run_2d_crank_nicolson
+    mask, edges, bcs = _one_pixel()
+    kw = dict(mask=mask, edges=edges, edge_conditions=bcs, initial_field=np.array([[2.0]]), diffusion_coefficient=6.0,
+              dt=0.1, total_time=0.2, dx=1.0, energy_gap=180.0, energy_min_factor=1.5, energy_max_factor=1.5,
+              num_energy_bins=1, enable_diffusion=False, enable_recombination=False, enable_scattering=False,
+              pauli_error_threshold=1.0)
+    with pytest.raises(ValueError, match="Pauli occupation exceeded limit"):
+        run_2d_crank_nicolson(**kw, enforce_pauli=True)
+    with pytest.warns(UserWarning, match="Pauli occupation exceeded limit"):
+        run_2d_crank_nicolson(**kw, enforce_pauli=False)
+
+
+def test_forbidden_state_is_detected():
+    """rho == 0 bins (E below the local gap) holding density trip the guard (solver.py:1305-1317)."""
+    from qpsim_amd.geometry import extract_edge_segments
+    from qpsim_amd.models import BoundaryCondition
+    from qpsim_amd.solver import run_2d_crank_nicolson
+    mask = np.ones((1, 4), dtype=bool)
+    edges = extract_edge_segments(mask)
+    bcs = {e.edge_id: BoundaryCondition("reflective") for e in edges}
+    with pytest.raises(ValueError, match="forbidden state"):
+        run_2d_crank_nicolson(mask=mask, edges=edges, edge_conditions=bcs, initial_field=np.full((1, 4), 1e-6),
+                              diffusion_coefficient=6.0, dt=0.1, total_time=0.1, dx=1.0, energy_gap=180.0,
+                              energy_min_factor=0.5, energy_max_factor=2.0, num_energy_bins=6,
+                              energy_weights=np.ones(6))
+
+
+def test_argument_errors_match_reference_types():
+    from qpsim_amd.engine import BoundaryAssignmentError
+    from qpsim_amd.solver import run_2d_crank_nicolson
+    mask, edges, bcs = _one_pixel()
+    base = dict(mask=mask, edges=edges, edge_conditions=bcs, initial_field=np.ones((1, 1)), diffusion_coefficient=1.0,
+                dt=0.1, total_time=0.2, dx=1.0)
+    with pytest.raises(ValueError):
+        run_2d_crank_nicolson(**{**base, "dt": 0.0})
+    with pytest.raises(ValueError):
+        run_2d_crank_nicolson(**{**base, "diffusion_coefficient": 0.0})
+    with pytest.raises(ValueError):
+        run_2d_crank_nicolson(**{**base, "initial_field": np.ones((2, 1))})
+    with pytest.raises(BoundaryAssignmentError):
+        run_2d_crank_nicolson(**{**base, "edge_conditions": {}})
+    with pytest.raises(ValueError, match="Unsupported collision solver"):
+        run_2d_crank_nicolson(**base, energy_gap=180.0, num_energy_bins=4, collision_solver="boltzphlow_relaxation")
+    with pytest.raises(ValueError, match="energy_weights must have length"):
+        run_2d_crank_nicolson(**base, energy_gap=180.0, num_energy_bins=4, energy_weights=np.ones(3))
+
+
+def test_progress_callback_and_final_time():
+    """tests/test_regressions.py:254-301."""
+    from qpsim_amd.geometry import extract_edge_segments
+    from qpsim_amd.models import BoundaryCondition
+    from qpsim_amd.solver import run_2d_crank_nicolson
+    mask = np.ones((2, 2), dtype=bool)
+    edges = extract_edge_segments(mask)
+    bcs = {e.edge_id: BoundaryCondition("reflective") for e in edges}
+    seen = []
+    times, frames, *_ = run_2d_crank_nicolson(mask, edges, bcs, np.ones((2, 2)), 1.0, 0.3, 1.0, 1.0, 1,
+                                              progress_callback=lambda t, f: seen.append((t, f.copy())))
+    assert abs(times[-1] - 1.0) < 1e-12 and len(times) == 5
+    assert [t for t, _ in seen] == times
+    assert np.allclose(seen[-1][1], frames[-1])
+
+    def boom(t, f):
+        raise RuntimeError("callback errors are swallowed")
+    run_2d_crank_nicolson(mask, edges, bcs, np.ones((2, 2)), 1.0, 0.3, 1.0, 1.0, 1, progress_callback=boom)
+
+
+def test_pauli_stats_kernel_tie_breaking_and_classes():
+    from qpsim_amd.engine import CompiledGeometry, Engine, link_flags
+    mask = np.ones((3, 5), dtype=bool)
+    mask[1, 2] = False
+    z = np.zeros(mask.shape)
+    eng = Engine(CompiledGeometry(mask, 1.0, link_flags(mask), z, z, z, z))
+    n = int(mask.sum())
+    rho = np.array([[1.0, 2.0, 0.0], [4.0, 0.0, 1.0]])
+    cls = np.arange(n) % 2
+    idx = np.zeros((3, 3), dtype=np.int32)
+    tab = eng.make_collision_tables(None, None, rho, idx, idx, idx.astype(np.int8), cls)
+    state = np.zeros((3, n))
+    state[0, 3] = 2.0      # class 1: f = 0.5
+    state[1, 4] = 1.0      # class 0: f = 0.5  (later in C order -> loses the tie)
+    state[0, 6] = 0.5      # class 0: f = 0.5  (same row, later pixel -> loses)
+    state[2, 8] = 1e-3     # class 0, rho = 0  -> forbidden
+    state[1, 9] = 5e-3     # class 1, rho = 0  -> forbidden, but earlier in C order (row 1 < row 2)
+    d = eng.upload_packed(state)
+    mx, top, forb = eng.pauli_stats(d, tab, 1e-18)
+    px_of_cell = np.cumsum(mask.reshape(-1)) - 1
+    assert mx == 0.5 and (top[0], px_of_cell[top[1]]) == (0, 3)
+    assert (forb[0], px_of_cell[forb[1]]) == (1, 9)
+    mx, top, forb = eng.pauli_stats(d, tab, 1.0)
+    assert forb is None
