@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: cell-updates/s of the N x N fp64 CN-ADI step (+ optional collision workloads).
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 the driver launches one rank
+per GPU with torch.distributed.run.  Rank 0 prints ONE JSON line.
+
+Workloads (``--workload``):
+  adi4096 (default)  4096 x 4096 scalar field, all-reflective full rectangle, D=6, dt=0.1, dx=1: one step =
+                     one Peaceman-Rachford CN-ADI step (both sweeps).  This is the configuration the metric
+                     and the >=40 %-of-HBM-roofline target of BASELINE.json are quoted on.
+  adi<N>             same at N x N (e.g. adi8192 for the cache-cold point, adi1024).
+  c2                 1024 x 1024, NE=12, recombination on, phonons frozen: Strang C(dt/2) D(dt) C(dt/2) per step
+                     (BASELINE configs[1]); cell-updates count NE diffusion updates per pixel per step.
+  c3                 4096 x 4096, NE=12, recombination + scattering with dynamic phonons (BASELINE configs[2]).
+
+Multi-GPU: independent problems per rank (ensemble sharding, no data-path collective) -> "scaling": "weak".
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+for _p in (str(ROOT), str(ROOT / "quasiparticle-physics-simulation_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # half of the 157.3 TF fp32 vector peak
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="adi4096")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-size", type=int, default=512, help="grid edge of the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+def full_rectangle_problem(N: int):
+    """SURVEY 8(d) synthetic inputs: full mask, reflective walls, dx=1, D0=6, dt=0.1, seeded initial field."""
+    from qpsim_amd.geometry import extract_edge_segments
+    from qpsim_amd.models import BoundaryCondition
+    mask = np.ones((N, N), dtype=bool)
+    edges = extract_edge_segments(mask)
+    bcs = {e.edge_id: BoundaryCondition("reflective") for e in edges}
+    init = 1e-4 * (1.0 + np.random.default_rng(0).random((N, N)))
+    return mask, edges, bcs, init
+
+
+def cpu_baseline(args, workload: str) -> dict:
+    """Reference algorithm (unsplit CN, SuperLU factor once + solve per step, solver.py:1545-1555) on host cores.
+
+    The oracle restatement is timed on a bounded sample: a cpu_size^2 grid of the same synthetic problem
+    (factorisation at 4096^2 is infeasible: fill-in grows super-linearly).
+    """
+    from oracle import qp_oracle as O
+    N = args.cpu_size
+    mask, edges, bcs, init = full_rectangle_problem(N)
+    t0 = time.perf_counter()
+    ops = O.build_grid_ops(mask, edges, bcs, 1.0)
+    st = O.CNStepper(ops, 6.0, 0.1)
+    t_setup = time.perf_counter() - t0
+    u = init[mask].astype(float)
+    steps = 0
+    t0 = time.perf_counter()
+    while True:
+        u = st.step(u)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > 8.0 or steps >= 200:
+            break
+    return {
+        "value": N * N * steps / el, "unit": "cell-updates/s", "cores": 1, "kind": "port",
+        "sample": (f"oracle unsplit-CN (SuperLU factor once, solve per step) on {N}x{N} scalar field, {steps} steps "
+                   f"in {el:.2f}s after {t_setup:.1f}s assembly+factorisation; single-threaded like the reference"),
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from qpsim_amd import bench_workloads as W
+
+    wl = W.build(args.workload, dev)
+    for _ in range(args.warmup):
+        wl.step()
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    sync()
+
+    # per-kernel timing of the dominant kernel with HIP events on the launch stream (same inputs, same loop)
+    roof = wl.roofline(max(5, min(args.steps, 20)))
+    value = wl.cell_updates_per_step * world * args.steps / elapsed
+    result = {
+        "metric": "cell-updates/sec on N×N CN ADI step; achieved HBM GB/s vs roofline",
+        "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": wl.description, "grid": wl.grid, "fields_per_gpu": wl.nfield,
+                   "parallelism": f"independent problems x{world} (no collective)" if world > 1 else "single GPU",
+                   "path": wl.path},
+        "roofline": roof,
+        "hbm_frac_of_step": (wl.bytes_per_step * args.steps / elapsed / 1e9) / HBM_PEAK_GBS,
+    }
+    if rank == 0:
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args, args.workload)
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

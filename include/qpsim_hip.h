@@ -148,6 +148,26 @@ int qp_absmax(const double* a, int64_t n, void* workspace, double* out_val, void
 /* y[i] += alpha * x[i] */
 int qp_axpy(int64_t n, double alpha, const double* x, double* y, void* stream);
 
+/*
+ * Fast CN-ADI path: full ny x nx rectangle, one diffusivity per field, one boundary condition per side.
+ * Replaces, for that geometry class, the whole `rhs = B u + dt D source; u = lu.solve(rhs)` loop of
+ * solver.py:1443-1452 / :1545-1555 by the Peaceman-Rachford factorisation of the same Crank-Nicolson step
+ * (identical when ny == 1 or nx == 1; O(dt^3) splitting term per step otherwise).
+ *
+ *   r          dt / (2 dx^2)
+ *   dcoef_host [nfield] diffusivities (HOST pointer; tables are built on the host at plan creation)
+ *   bc_diag    [4] boundary diagonal terms of the left, right, up, down sides in 1/dx^2 units (see ex/ey above)
+ *   bc_src     [4] boundary source terms of the same sides (see sx/sy above)
+ * The plan owns its device tables and work planes (hipMalloc at creation, the only allocating call).
+ * qp_adi_rect_steps advances u [nfield][ny*nx] in place by `nsteps` consecutive diffusion steps; intermediate
+ * fields are not materialised (steady-state traffic: one read + one write of the field per sweep).
+ */
+typedef struct qp_adi_rect_plan qp_adi_rect_plan;
+int qp_adi_rect_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, const double* dcoef_host,
+                            const double* bc_diag, const double* bc_src, qp_adi_rect_plan** out);
+int qp_adi_rect_plan_destroy(qp_adi_rect_plan* plan);
+int qp_adi_rect_steps(qp_adi_rect_plan* plan, double* u, int32_t nsteps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

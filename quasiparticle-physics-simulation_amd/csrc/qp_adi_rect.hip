@@ -1,0 +1,508 @@
+// Fast CN-ADI path for full rectangles with one diffusivity per field and one boundary condition per side.
+//
+// Peaceman-Rachford step, a = r D (r = dt / (2 dx^2)):
+//     (I - a Lx) u*  = (I + a Ly) u  + a S          S = boundary-face sources (1/dx^2 units)
+//     (I - a Ly) u'  = (I + a Lx) u* + a S
+// Every grid line is cut into chunks of 64 cells (the edge of a 64 x 64 tile).  A line system A x = d is solved
+// by the partition (SPIKE) method:
+//     local   y_p = A_p^-1 d_p                       (per chunk, no communication)
+//     reduced F_p, E_p = first / last unknown of chunk p from a banded 2P x 2P system whose right-hand side is
+//             (y_p[0], y_p[last]) = (g_p . d_p, h_p . d_p),  g_p, h_p = first / last column of A_p^-1
+//     final   A_p x_p = d_p + a E_{p-1} e_first + a F_{p+1} e_last       (per chunk again)
+// A_p, g_p, h_p and the LU factors of the reduced matrix depend only on (field, direction, chunk position), so
+// the host tabulates them once per plan and the kernels read them as wave-uniform scalars.
+//
+// One wave owns one 64 x 64 tile.  Two tile kernels alternate, each reading and writing every cell once:
+//   x-kernel:  load d (rhs of the x-solve) -> finish the x-solve with the ghost values E/F -> u* ->
+//              rhs2 = (I + a Lx) u* + a S -> store -> dot products g_y, h_y per column -> reduced rhs for y
+//   y-kernel:  load rhs2 -> finish the y-solve -> u' -> [store u' | rhs1' = (I + a Ly) u' + a S -> store ->
+//              dot products g_x, h_x per row -> reduced rhs for the NEXT step's x-solve]
+// plus a one-thread-per-line kernel for the banded reduced systems.  Consecutive diffusion steps therefore cost
+// 2 x (8 B read + 8 B write) = 32 B per cell-update; a step that starts from a materialised field u pays one
+// extra pass (the "entry" variant of the y-kernel forms rhs1 from u and its two halo rows).
+//
+// Global accesses: lane <-> column, one 512 B row segment per wave instruction.  x-direction work needs
+// lane <-> row, so the tile goes through LDS (pitch 65 doubles: conflict-free both ways) at each change of
+// direction.  y-direction work happens entirely in registers (64 doubles per lane).
+#include <vector>
+
+#include "qp_common.h"
+
+namespace qp {
+
+constexpr int TS = 64;          // tile edge = chunk length
+constexpr int PITCH = TS + 1;   // LDS row pitch in doubles
+
+// table slots per (direction, field, chunk variant); each slot is TS doubles
+enum { T_W = 0, T_AWF, T_AWB, T_CM, T_C0, T_CP, T_SRC, T_G, T_H, T_NSLOT };
+
+struct RectDims {
+  int ny, nx, nfield;
+  int py, px;                   // chunks per column / per row
+};
+
+struct RectView {
+  RectDims d;
+  const double* alpha;          // [nfield]
+  const double* tab;            // [2 dirs][nfield][4 variants][T_NSLOT][TS]
+  const double* lu[2];          // per dir: [nfield][5][2P]  (l1, l2, uinv, u1, u2)
+  double* iface[2];             // per dir: [nfield][2P][nlines]   reduced right-hand sides
+  double* z[2];                 // per dir: [nfield][2P][nlines]   reduced solutions (F_0, E_0, F_1, E_1, ...)
+  double other_src[2][2];       // [dir][lo/hi]: a-less source of the faces normal to `dir` (x: sx_lo, sx_hi)
+};
+
+__device__ __forceinline__ int chunk_variant(int p, int P) {
+  // 0 interior, 1 first, 2 last, 3 single
+  return (p == 0 ? 1 : 0) | (p == P - 1 ? 2 : 0);
+}
+
+__device__ __forceinline__ const double* table_ptr(const RectView& v, int dir, int b, int variant) {
+  return v.tab + ((((long)dir * v.d.nfield + b) * 4 + variant) * T_NSLOT) * TS;
+}
+
+// Thomas solve of one chunk held in registers; padded entries (k >= chunk length) carry w = 1, aw = 0.
+__device__ __forceinline__ void thomas64(double (&e)[TS], const double* __restrict__ t) {
+  double dp = 0.0;
+#pragma unroll
+  for (int k = 0; k < TS; ++k) {
+    dp = fma(t[T_AWF * TS + k], dp, e[k] * t[T_W * TS + k]);
+    e[k] = dp;
+  }
+  double x = 0.0;
+#pragma unroll
+  for (int k = TS - 1; k >= 0; --k) {
+    x = fma(t[T_AWB * TS + k], x, e[k]);
+    e[k] = x;
+  }
+}
+
+// e <- (I + a L) e + a s along the chunk, with neighbour values gl / gr beyond its ends, plus `extra` on valid cells.
+__device__ __forceinline__ void explicit64(double (&e)[TS], double gl, double gr, const double* __restrict__ t,
+                                           double extra, int len) {
+  double prev = gl;
+#pragma unroll
+  for (int k = 0; k < TS; ++k) {
+    const double cur = e[k];
+    const double nxt = (k + 1 < TS) ? e[k + 1] : gr;
+    double out = fma(t[T_CM * TS + k], prev, fma(t[T_CP * TS + k], nxt, fma(t[T_C0 * TS + k], cur, t[T_SRC * TS + k])));
+    out += (k < len) ? extra : 0.0;
+    e[k] = out;
+    prev = cur;
+  }
+}
+
+__device__ __forceinline__ void dots64(const double (&e)[TS], const double* __restrict__ t, double& yf, double& yl) {
+  double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+  for (int k = 0; k < TS; ++k) {
+    a0 = fma(t[T_G * TS + k], e[k], a0);
+    a1 = fma(t[T_H * TS + k], e[k], a1);
+  }
+  yf = a0;
+  yl = a1;
+}
+
+// registers (lane = column, index = row)  ->  registers (lane = row, index = column), through LDS
+__device__ __forceinline__ void transpose_c2r(double (&v)[TS], double* lds, int lane) {
+#pragma unroll
+  for (int r = 0; r < TS; ++r) lds[r * PITCH + lane] = v[r];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < TS; ++k) v[k] = lds[lane * PITCH + k];
+  __syncthreads();
+}
+
+__device__ __forceinline__ void transpose_r2c(double (&v)[TS], double* lds, int lane) {
+#pragma unroll
+  for (int k = 0; k < TS; ++k) lds[lane * PITCH + k] = v[k];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < TS; ++r) v[r] = lds[r * PITCH + lane];
+  __syncthreads();
+}
+
+struct TileCoord {
+  int b, ty, tx, j0, i0, nr, nc;
+};
+
+__device__ __forceinline__ TileCoord tile_coord(const RectDims& d) {
+  TileCoord t;
+  int id = blockIdx.x;
+  t.tx = id % d.px;
+  id /= d.px;
+  t.ty = id % d.py;
+  t.b = id / d.py;
+  t.j0 = t.ty * TS;
+  t.i0 = t.tx * TS;
+  t.nr = min(TS, d.ny - t.j0);
+  t.nc = min(TS, d.nx - t.i0);
+  return t;
+}
+
+__device__ __forceinline__ void load_cols(const double* __restrict__ base, const TileCoord& t, int nx, int lane,
+                                          double (&v)[TS]) {
+  const bool on = lane < t.nc;
+  const double* p = base + (long)t.j0 * nx + t.i0 + lane;
+#pragma unroll
+  for (int r = 0; r < TS; ++r) v[r] = (on && r < t.nr) ? p[(long)r * nx] : 0.0;
+}
+
+__device__ __forceinline__ void store_cols(double* __restrict__ base, const TileCoord& t, int nx, int lane,
+                                           const double (&v)[TS]) {
+  if (lane >= t.nc) return;
+  double* p = base + (long)t.j0 * nx + t.i0 + lane;
+#pragma unroll
+  for (int r = 0; r < TS; ++r)
+    if (r < t.nr) p[(long)r * nx] = v[r];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// x-kernel: finish the x-solve, apply the explicit x-operator, eliminate along y.   buf: rhs1 -> rhs2 in place
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) rect_x_kernel(RectView v, double* __restrict__ buf) {
+  __shared__ double lds[TS * PITCH];
+  const int lane = threadIdx.x;
+  const TileCoord t = tile_coord(v.d);
+  const long ncell = (long)v.d.ny * v.d.nx;
+  double* plane = buf + (long)t.b * ncell;
+  const double a = v.alpha[t.b];
+  double e[TS];
+  load_cols(plane, t, v.d.nx, lane, e);
+  transpose_c2r(e, lds, lane);
+  // lane = row from here
+  const int row = t.j0 + lane;
+  const bool row_on = lane < t.nr;
+  const double* zx = v.z[0] + (long)t.b * 2 * v.d.px * v.d.ny;
+  const double gl = (row_on && t.tx > 0) ? zx[(long)(2 * t.tx - 1) * v.d.ny + row] : 0.0;
+  const double gr = (row_on && t.tx < v.d.px - 1) ? zx[(long)(2 * t.tx + 2) * v.d.ny + row] : 0.0;
+  const double* tx_tab = table_ptr(v, 0, t.b, chunk_variant(t.tx, v.d.px));
+  e[0] = fma(a, gl, e[0]);
+  e[TS - 1] = fma(a, gr, e[TS - 1]);   // gr != 0 only for full-length chunks
+  thomas64(e, tx_tab);
+  double srow = 0.0;                   // sources of the y-faces (up/down) belong to rows 0 and ny-1
+  if (row == 0) srow += a * v.other_src[1][0];
+  if (row == v.d.ny - 1) srow += a * v.other_src[1][1];
+  explicit64(e, gl, gr, tx_tab, row_on ? srow : 0.0, t.nc);
+  transpose_r2c(e, lds, lane);
+  // lane = column again
+  store_cols(plane, t, v.d.nx, lane, e);
+  double yf, yl;
+  dots64(e, table_ptr(v, 1, t.b, chunk_variant(t.ty, v.d.py)), yf, yl);
+  if (lane < t.nc) {
+    double* ir = v.iface[1] + (long)t.b * 2 * v.d.py * v.d.nx;
+    ir[(long)(2 * t.ty) * v.d.nx + t.i0 + lane] = yf;
+    ir[(long)(2 * t.ty + 1) * v.d.nx + t.i0 + lane] = yl;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// y-kernel.  MODE 0 (entry): src = u, no solve, halo rows from u;  dst = rhs1, x-elimination
+//            MODE 1 (carry): src = rhs2, y-solve, rhs1' = (I + a Ly) u' + a S; dst = rhs1', x-elimination
+//            MODE 2 (exit):  src = rhs2, y-solve, dst = u'
+// ---------------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(64) rect_y_kernel(RectView v, const double* src, double* dst) {  // src may alias dst
+  __shared__ double lds[TS * PITCH];
+  const int lane = threadIdx.x;
+  const TileCoord t = tile_coord(v.d);
+  const long ncell = (long)v.d.ny * v.d.nx;
+  const double* splane = src + (long)t.b * ncell;
+  double* dplane = dst + (long)t.b * ncell;
+  const double a = v.alpha[t.b];
+  const int col = t.i0 + lane;
+  const bool col_on = lane < t.nc;
+  const double* ty_tab = table_ptr(v, 1, t.b, chunk_variant(t.ty, v.d.py));
+  double e[TS];
+  load_cols(splane, t, v.d.nx, lane, e);
+  double gu = 0.0, gd = 0.0;           // values of the field just above / below the tile
+  if (MODE == 0) {
+    if (col_on && t.ty > 0) gu = splane[(long)(t.j0 - 1) * v.d.nx + col];
+    if (col_on && t.ty < v.d.py - 1) gd = splane[(long)(t.j0 + TS) * v.d.nx + col];
+  } else {
+    const double* zy = v.z[1] + (long)t.b * 2 * v.d.py * v.d.nx;
+    if (col_on && t.ty > 0) gu = zy[(long)(2 * t.ty - 1) * v.d.nx + col];
+    if (col_on && t.ty < v.d.py - 1) gd = zy[(long)(2 * t.ty + 2) * v.d.nx + col];
+    e[0] = fma(a, gu, e[0]);
+    e[TS - 1] = fma(a, gd, e[TS - 1]);
+    thomas64(e, ty_tab);
+  }
+  if (MODE == 2) {
+    store_cols(dplane, t, v.d.nx, lane, e);
+    return;
+  }
+  double scol = 0.0;                   // sources of the x-faces (left/right) belong to columns 0 and nx-1
+  if (col == 0) scol += a * v.other_src[0][0];
+  if (col == v.d.nx - 1) scol += a * v.other_src[0][1];
+  explicit64(e, gu, gd, ty_tab, col_on ? scol : 0.0, t.nr);
+  store_cols(dplane, t, v.d.nx, lane, e);
+  transpose_c2r(e, lds, lane);
+  double yf, yl;
+  dots64(e, table_ptr(v, 0, t.b, chunk_variant(t.tx, v.d.px)), yf, yl);
+  if (lane < t.nr) {
+    double* ir = v.iface[0] + (long)t.b * 2 * v.d.px * v.d.ny;
+    ir[(long)(2 * t.tx) * v.d.ny + t.j0 + lane] = yf;
+    ir[(long)(2 * t.tx + 1) * v.d.ny + t.j0 + lane] = yl;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// reduced banded systems: one thread per (field, line); unknown order F_0, E_0, F_1, E_1, ...
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) rect_reduced_kernel(RectView v, int dir) {
+  const int nlines = dir == 0 ? v.d.ny : v.d.nx;
+  const int m = 2 * (dir == 0 ? v.d.px : v.d.py);
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)nlines * v.d.nfield) return;
+  const int b = (int)(gid / nlines);
+  const int line = (int)(gid - (long)b * nlines);
+  const double* lu = v.lu[dir] + (long)b * 5 * m;
+  const double* rhs = v.iface[dir] + (long)b * m * nlines + line;
+  double* z = v.z[dir] + (long)b * m * nlines + line;
+  double y1 = 0.0, y2 = 0.0;  // y_{i-1}, y_{i-2}
+  for (int i = 0; i < m; ++i) {
+    const double y = rhs[(long)i * nlines] - lu[i] * y1 - lu[m + i] * y2;
+    z[(long)i * nlines] = y;
+    y2 = y1;
+    y1 = y;
+  }
+  double z1 = 0.0, z2 = 0.0;  // z_{i+1}, z_{i+2}
+  for (int i = m - 1; i >= 0; --i) {
+    const double zi = (z[(long)i * nlines] - lu[3 * m + i] * z1 - lu[4 * m + i] * z2) * lu[2 * m + i];
+    z[(long)i * nlines] = zi;
+    z2 = z1;
+    z1 = zi;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side: tables, plan
+// ---------------------------------------------------------------------------------------------------------
+struct DirSpec {
+  int n;          // line length
+  int P;          // chunks
+  double e_lo, e_hi;   // BC diagonal terms of the two end faces (1/dx^2 units)
+  double s_lo, s_hi;   // BC sources of the two end faces
+};
+
+static void chunk_diagonal(const DirSpec& s, double a, int p, int len, std::vector<double>& bdiag) {
+  bdiag.assign(len, 0.0);
+  for (int k = 0; k < len; ++k) {
+    const int gk = p * TS + k;
+    const double links = (gk > 0 ? 1.0 : 0.0) + (gk < s.n - 1 ? 1.0 : 0.0);
+    const double e = (gk == 0 ? s.e_lo : 0.0) + (gk == s.n - 1 ? s.e_hi : 0.0);
+    bdiag[k] = 1.0 + a * (links + e);
+  }
+}
+
+static void solve_chunk(const std::vector<double>& bdiag, double a, std::vector<double>& rhs) {
+  const int len = (int)bdiag.size();
+  std::vector<double> w(len);
+  double dp = 0.0;
+  for (int k = 0; k < len; ++k) {
+    w[k] = 1.0 / (bdiag[k] - (k > 0 ? a * a * w[k - 1] : 0.0));
+    dp = (rhs[k] + (k > 0 ? a * dp : 0.0)) * w[k];
+    rhs[k] = dp;
+  }
+  for (int k = len - 2; k >= 0; --k) rhs[k] += a * w[k] * rhs[k + 1];
+}
+
+// fills the T_NSLOT x TS table of chunk `p`; returns g[0], g[last], h[0], h[last] through `ends`
+static void build_chunk_table(const DirSpec& s, double a, int p, double* tab, double ends[4]) {
+  const int len = std::min(TS, s.n - p * TS);
+  std::vector<double> bd;
+  chunk_diagonal(s, a, p, len, bd);
+  for (int k = 0; k < TS * T_NSLOT; ++k) tab[k] = 0.0;
+  double wprev = 0.0;
+  for (int k = 0; k < TS; ++k) {
+    if (k < len) {
+      const double w = 1.0 / (bd[k] - (k > 0 ? a * a * wprev : 0.0));
+      tab[T_W * TS + k] = w;
+      tab[T_AWF * TS + k] = k > 0 ? a * w : 0.0;
+      tab[T_AWB * TS + k] = k < len - 1 ? a * w : 0.0;
+      wprev = w;
+      const int gk = p * TS + k;
+      const bool lm = gk > 0, lp = gk < s.n - 1;
+      const double e = (gk == 0 ? s.e_lo : 0.0) + (gk == s.n - 1 ? s.e_hi : 0.0);
+      tab[T_CM * TS + k] = lm ? a : 0.0;
+      tab[T_CP * TS + k] = lp ? a : 0.0;
+      tab[T_C0 * TS + k] = 1.0 - a * ((lm ? 1.0 : 0.0) + (lp ? 1.0 : 0.0) + e);
+      tab[T_SRC * TS + k] = a * ((gk == 0 ? s.s_lo : 0.0) + (gk == s.n - 1 ? s.s_hi : 0.0));
+    } else {
+      tab[T_W * TS + k] = 1.0;
+    }
+  }
+  std::vector<double> g(len, 0.0), h(len, 0.0);
+  g[0] = 1.0;
+  h[len - 1] = 1.0;
+  solve_chunk(bd, a, g);
+  solve_chunk(bd, a, h);
+  for (int k = 0; k < len; ++k) {
+    tab[T_G * TS + k] = g[k];
+    tab[T_H * TS + k] = h[k];
+  }
+  ends[0] = g[0];
+  ends[1] = g[len - 1];
+  ends[2] = h[0];
+  ends[3] = h[len - 1];
+}
+
+// banded LU (2 sub-, 2 super-diagonals, no pivoting: the matrix is strictly diagonally dominant)
+static void reduced_lu(const DirSpec& s, double a, double* lu /*[5][2P]*/) {
+  const int m = 2 * s.P;
+  std::vector<double> A((size_t)m * m, 0.0);
+  std::vector<double> tab(TS * T_NSLOT);
+  for (int p = 0; p < s.P; ++p) {
+    double ends[4];
+    build_chunk_table(s, a, p, tab.data(), ends);
+    const int f = 2 * p, e = 2 * p + 1;
+    A[(size_t)f * m + f] = 1.0;
+    A[(size_t)e * m + e] = 1.0;
+    if (p > 0) {
+      A[(size_t)f * m + (2 * p - 1)] += -a * ends[0];
+      A[(size_t)e * m + (2 * p - 1)] += -a * ends[1];
+    }
+    if (p < s.P - 1) {
+      A[(size_t)f * m + (2 * p + 2)] += -a * ends[2];
+      A[(size_t)e * m + (2 * p + 2)] += -a * ends[3];
+    }
+  }
+  for (int k = 0; k < m; ++k) {
+    for (int i = k + 1; i < std::min(m, k + 3); ++i) {
+      const double l = A[(size_t)i * m + k] / A[(size_t)k * m + k];
+      A[(size_t)i * m + k] = l;
+      for (int j = k + 1; j < std::min(m, k + 5); ++j) A[(size_t)i * m + j] -= l * A[(size_t)k * m + j];
+    }
+  }
+  for (int i = 0; i < m; ++i) {
+    lu[i] = i >= 1 ? A[(size_t)i * m + i - 1] : 0.0;
+    lu[m + i] = i >= 2 ? A[(size_t)i * m + i - 2] : 0.0;
+    lu[2 * m + i] = 1.0 / A[(size_t)i * m + i];
+    lu[3 * m + i] = i + 1 < m ? A[(size_t)i * m + i + 1] : 0.0;
+    lu[4 * m + i] = i + 2 < m ? A[(size_t)i * m + i + 2] : 0.0;
+  }
+}
+
+}  // namespace qp
+
+struct qp_adi_rect_plan {
+  qp::RectView view;
+  double* d_alpha = nullptr;
+  double* d_tab = nullptr;
+  double* d_lu[2] = {nullptr, nullptr};
+  double* d_iface[2] = {nullptr, nullptr};
+  double* d_z[2] = {nullptr, nullptr};
+  double* d_work = nullptr;  // [nfield][ncell] carried right-hand side
+  long ncell = 0;
+};
+
+extern "C" {
+
+int qp_adi_rect_plan_destroy(qp_adi_rect_plan* plan) {
+  if (!plan) return QP_OK;
+  (void)hipFree(plan->d_alpha);
+  (void)hipFree(plan->d_tab);
+  for (int d = 0; d < 2; ++d) {
+    (void)hipFree(plan->d_lu[d]);
+    (void)hipFree(plan->d_iface[d]);
+    (void)hipFree(plan->d_z[d]);
+  }
+  (void)hipFree(plan->d_work);
+  delete plan;
+  return QP_OK;
+}
+
+int qp_adi_rect_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, const double* dcoef_host,
+                            const double* bc_diag, const double* bc_src, qp_adi_rect_plan** out) {
+  QP_REQUIRE(out != nullptr, "out is NULL");
+  *out = nullptr;
+  QP_REQUIRE(ny > 0 && nx > 0 && nfield > 0, "ny, nx, nfield must be positive");
+  QP_REQUIRE(r > 0.0 && dcoef_host && bc_diag && bc_src, "r must be positive; dcoef/bc arrays non-NULL");
+  for (int b = 0; b < nfield; ++b) QP_REQUIRE(dcoef_host[b] >= 0.0, "diffusion coefficients must be >= 0");
+  using namespace qp;
+  auto* plan = new qp_adi_rect_plan();
+  RectView& v = plan->view;
+  v.d = RectDims{ny, nx, nfield, (ny + TS - 1) / TS, (nx + TS - 1) / TS};
+  plan->ncell = (long)ny * nx;
+  // bc_* order: left, right, up, down  (x-faces then y-faces)
+  DirSpec spec[2] = {{nx, v.d.px, bc_diag[0], bc_diag[1], bc_src[0], bc_src[1]},
+                     {ny, v.d.py, bc_diag[2], bc_diag[3], bc_src[2], bc_src[3]}};
+  v.other_src[0][0] = bc_src[0];
+  v.other_src[0][1] = bc_src[1];
+  v.other_src[1][0] = bc_src[2];
+  v.other_src[1][1] = bc_src[3];
+
+  std::vector<double> alpha(nfield);
+  std::vector<double> tab((size_t)2 * nfield * 4 * T_NSLOT * TS, 0.0);
+  std::vector<double> lu[2];
+  for (int d = 0; d < 2; ++d) lu[d].assign((size_t)nfield * 5 * 2 * spec[d].P, 0.0);
+  for (int b = 0; b < nfield; ++b) {
+    const double a = r * dcoef_host[b];
+    alpha[b] = a;
+    for (int d = 0; d < 2; ++d) {
+      const int P = spec[d].P;
+      // representative chunk per variant: interior -> 1, first -> 0, last -> P-1, single -> 0
+      for (int var = 0; var < 4; ++var) {
+        int p;
+        if (var == 0) { if (P < 3) continue; p = 1; }
+        else if (var == 1) { if (P < 2) continue; p = 0; }
+        else if (var == 2) { if (P < 2) continue; p = P - 1; }
+        else { if (P != 1) continue; p = 0; }
+        double ends[4];
+        build_chunk_table(spec[d], a, p, &tab[((((size_t)d * nfield + b) * 4 + var) * T_NSLOT) * TS], ends);
+      }
+      reduced_lu(spec[d], a, &lu[d][(size_t)b * 5 * 2 * P]);
+    }
+  }
+  auto upload = [](const std::vector<double>& h, double** dptr) -> bool {
+    if (hipMalloc((void**)dptr, h.size() * sizeof(double)) != hipSuccess) return false;
+    return hipMemcpy(*dptr, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+  };
+  bool ok = upload(alpha, &plan->d_alpha) && upload(tab, &plan->d_tab);
+  for (int d = 0; d < 2 && ok; ++d) {
+    const size_t nlines = d == 0 ? ny : nx;
+    const size_t cnt = (size_t)nfield * 2 * spec[d].P * nlines;
+    ok = upload(lu[d], &plan->d_lu[d]) && hipMalloc((void**)&plan->d_iface[d], cnt * sizeof(double)) == hipSuccess &&
+         hipMalloc((void**)&plan->d_z[d], cnt * sizeof(double)) == hipSuccess;
+  }
+  ok = ok && hipMalloc((void**)&plan->d_work, (size_t)nfield * plan->ncell * sizeof(double)) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    qp_adi_rect_plan_destroy(plan);
+    set_error("qp_adi_rect_plan_create: device allocation or upload failed");
+    return QP_ERR_ALLOC;
+  }
+  v.alpha = plan->d_alpha;
+  v.tab = plan->d_tab;
+  for (int d = 0; d < 2; ++d) {
+    v.lu[d] = plan->d_lu[d];
+    v.iface[d] = plan->d_iface[d];
+    v.z[d] = plan->d_z[d];
+  }
+  *out = plan;
+  return QP_OK;
+}
+
+int qp_adi_rect_steps(qp_adi_rect_plan* plan, double* u, int32_t nsteps, void* stream_) {
+  QP_REQUIRE(plan && u, "plan and u must be non-NULL");
+  QP_REQUIRE(nsteps >= 1, "nsteps must be >= 1");
+  using namespace qp;
+  hipStream_t stream = (hipStream_t)stream_;
+  const RectView& v = plan->view;
+  const unsigned tiles = (unsigned)((long)v.d.nfield * v.d.py * v.d.px);
+  const unsigned redx = (unsigned)(((long)v.d.ny * v.d.nfield + 63) / 64);
+  const unsigned redy = (unsigned)(((long)v.d.nx * v.d.nfield + 63) / 64);
+  double* w = plan->d_work;
+  hipLaunchKernelGGL(rect_y_kernel<0>, dim3(tiles), dim3(64), 0, stream, v, (const double*)u, w);
+  for (int s = 0; s < nsteps; ++s) {
+    hipLaunchKernelGGL(rect_reduced_kernel, dim3(redx), dim3(64), 0, stream, v, 0);
+    hipLaunchKernelGGL(rect_x_kernel, dim3(tiles), dim3(64), 0, stream, v, w);
+    hipLaunchKernelGGL(rect_reduced_kernel, dim3(redy), dim3(64), 0, stream, v, 1);
+    if (s + 1 < nsteps)
+      hipLaunchKernelGGL(rect_y_kernel<1>, dim3(tiles), dim3(64), 0, stream, v, (const double*)w, w);
+    else
+      hipLaunchKernelGGL(rect_y_kernel<2>, dim3(tiles), dim3(64), 0, stream, v, (const double*)w, u);
+  }
+  return check_launch("qp_adi_rect_steps");
+}
+
+}  // extern "C"

@@ -147,10 +147,64 @@ def _ptr(t) -> int:
     return 0 if t is None else int(t.data_ptr())
 
 
+def rect_side_terms(geom: CompiledGeometry):
+    """(bc_diag[4], bc_src[4]) in left, right, up, down order if the geometry is a full rectangle whose four
+    sides each carry one boundary condition; None otherwise (then only the general kernels apply)."""
+    if not geom.is_full_rectangle:
+        return None
+    ny, nx = geom.mask.shape
+
+    def side(arr, sl):
+        vals = arr[sl]
+        return float(vals.flat[0]) if np.all(vals == vals.flat[0]) else None
+
+    if nx > 1:
+        xs = [side(geom.ex, (slice(None), 0)), side(geom.ex, (slice(None), -1)),
+              side(geom.sx, (slice(None), 0)), side(geom.sx, (slice(None), -1))]
+    else:  # one column: both x-faces sit on the same cell; only their sum enters
+        xs = [side(geom.ex, (slice(None), 0)), 0.0, side(geom.sx, (slice(None), 0)), 0.0]
+    if ny > 1:
+        ys = [side(geom.ey, (0, slice(None))), side(geom.ey, (-1, slice(None))),
+              side(geom.sy, (0, slice(None))), side(geom.sy, (-1, slice(None)))]
+    else:
+        ys = [side(geom.ey, (0, slice(None))), 0.0, side(geom.sy, (0, slice(None))), 0.0]
+    if any(v is None for v in xs + ys):
+        return None
+    return [xs[0], xs[1], ys[0], ys[1]], [xs[2], xs[3], ys[2], ys[3]]
+
+
+class RectPlan:
+    """Owner of a ``qp_adi_rect_plan`` (device tables + work planes of the fast full-rectangle ADI path)."""
+
+    def __init__(self, lib, ny, nx, nfield, r, dcoef, bc_diag, bc_src):
+        self._lib = lib
+        self._h = C.POINTER(_hip.RectPlan)()
+        dc = (C.c_double * nfield)(*[float(v) for v in dcoef])
+        bd = (C.c_double * 4)(*bc_diag)
+        bs = (C.c_double * 4)(*bc_src)
+        _hip.check(lib.qp_adi_rect_plan_create(ny, nx, nfield, float(r), dc, bd, bs, C.byref(self._h)),
+                   "qp_adi_rect_plan_create")
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            self._lib.qp_adi_rect_plan_destroy(self._h)
+            self._h = C.POINTER(_hip.RectPlan)()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DiffusionOperator:
     """(I - r L_x), (I - r L_y) and friends for one time step size on a batch of fields."""
 
-    def __init__(self, engine: "Engine", nfield: int, dt: float, dcoef=None, dfield=None):
+    def __init__(self, engine: "Engine", nfield: int, dt: float, dcoef=None, dfield=None, allow_fast: bool = True):
         torch = engine.torch
         self.engine = engine
         self.nfield = int(nfield)
@@ -164,6 +218,13 @@ class DiffusionOperator:
         g = engine
         self.desc = _hip.GridDesc(g.ny, g.nx, self.nfield, _ptr(g.d_flags), _ptr(g.d_ex), _ptr(g.d_ey), _ptr(g.d_sx),
                                   _ptr(g.d_sy), _ptr(self.dcoef), _ptr(self.dfield))
+        # full rectangle + one D per field + one BC per side -> tiled partition-method kernels
+        self.rect = None
+        sides = rect_side_terms(engine.geom) if (allow_fast and dcoef is not None) else None
+        if sides is not None and self.dt > 0.0:
+            with torch.cuda.device(engine.device):
+                self.rect = RectPlan(engine.lib, g.ny, g.nx, self.nfield, self.r, np.asarray(dcoef, dtype=float),
+                                     sides[0], sides[1])
 
 
 class Engine:
@@ -222,8 +283,22 @@ class Engine:
         _hip.check(self.lib.qp_implicit_sweep(C.byref(op.desc), op.r, direction, _ptr(rhs), _ptr(x), _ptr(scr),
                                               self.stream), "qp_implicit_sweep")
 
+    def adi_steps(self, op: DiffusionOperator, u, nsteps: int = 1):
+        """`nsteps` consecutive Peaceman-Rachford steps in place (fast path carries the state between steps)."""
+        if op.rect is not None:
+            _hip.check(self.lib.qp_adi_rect_steps(op.rect.handle, _ptr(u), int(nsteps), self.stream), "qp_adi_rect_steps")
+            return u
+        for _ in range(int(nsteps)):
+            self.adi_step(op, u)
+        return u
+
     def adi_step(self, op: DiffusionOperator, u, out=None):
-        """Peaceman-Rachford step: (I-rLx)u* = (I+rLy)u + rS; (I-rLy)u' = (I+rLx)u* + rS.  Returns u' (new tensor or `out`)."""
+        """Peaceman-Rachford step: (I-rLx)u* = (I+rLy)u + rS; (I-rLy)u' = (I+rLx)u* + rS.  In place unless `out`."""
+        if op.rect is not None:
+            if out is not None:
+                out.copy_(u)
+                u = out
+            return self.adi_steps(op, u, 1)
         n = op.nfield * self.ncell
         t1 = self.scratch("adi_t1", n).view(op.nfield, self.ncell)
         t2 = self.scratch("adi_t2", n).view(op.nfield, self.ncell)

@@ -323,3 +323,61 @@ def test_pauli_stats_kernel_tie_breaking_and_classes():
     assert (forb[0], px_of_cell[forb[1]]) == (1, 9)
     mx, top, forb = eng.pauli_stats(d, tab, 1.0)
     assert forb is None
+
+
+@pytest.mark.parametrize("ny,nx", [(64, 64), (128, 192), (1, 48), (50, 1), (1, 1), (3, 200), (70, 65), (129, 257), (64, 63)])
+def test_rect_fast_path_matches_oracle_adi_and_general_kernels(O, ny, nx):
+    """Tiled partition-method ADI (full rectangle, one BC per side) vs the oracle ADI and the general kernels."""
+    from qpsim_amd.engine import DiffusionOperator, Engine, compile_geometry
+    from qpsim_amd.geometry import extract_edge_segments
+    from qpsim_amd.models import BoundaryCondition
+    rng = np.random.default_rng(ny * 1000 + nx)
+    mask = np.ones((ny, nx), dtype=bool)
+    edges = extract_edge_segments(mask)
+    side_bc = {"left": BoundaryCondition("dirichlet", 0.7), "right": BoundaryCondition("robin", 0.4, 0.2),
+               "up": BoundaryCondition("neumann", -0.3), "down": BoundaryCondition("absorbing")}
+    bcs = {e.edge_id: side_bc[e.normal] for e in edges}
+    dx, dt = 0.9, 0.11
+    geom = compile_geometry(mask, edges, bcs, dx)
+    eng = Engine(geom)
+    ops = O.build_grid_ops(mask, edges, bcs, dx)
+    Dc = [6.0, 0.35, 0.0, 40.0]
+    u0 = rng.random((len(Dc), ny * nx))
+    fast = DiffusionOperator(eng, len(Dc), dt, dcoef=Dc)
+    slow = DiffusionOperator(eng, len(Dc), dt, dcoef=Dc, allow_fast=False)
+    assert fast.rect is not None and slow.rect is None
+    for nsteps in (1, 3):
+        a = eng.upload_packed(u0)
+        b = eng.upload_packed(u0)
+        eng.adi_steps(fast, a, nsteps)
+        eng.adi_steps(slow, b, nsteps)
+        ha, hb = eng.download_packed(a), eng.download_packed(b)
+        for k, D in enumerate(Dc):
+            st = O.ADIStepper(ops, D, dt)
+            want = u0[k].copy()
+            for _ in range(nsteps):
+                want = st.step(want)
+            assert rel_err(ha[k], want) < 2e-13, (k, nsteps)
+            assert rel_err(hb[k], want) < 2e-13, (k, nsteps)
+
+
+def test_rect_fast_path_large_reflective_conserves_mass_and_matches_general():
+    """4096-class property check at a size the oracle cannot reach quickly: 1024^2, 5 steps, reflective walls."""
+    from qpsim_amd.engine import DiffusionOperator, Engine, compile_geometry
+    from qpsim_amd.geometry import extract_edge_segments
+    from qpsim_amd.models import BoundaryCondition
+    N = 1024
+    mask = np.ones((N, N), dtype=bool)
+    edges = extract_edge_segments(mask)
+    bcs = {e.edge_id: BoundaryCondition("reflective") for e in edges}
+    eng = Engine(compile_geometry(mask, edges, bcs, 1.0))
+    u0 = 1e-4 * (1.0 + np.random.default_rng(0).random((1, N * N)))
+    fast = DiffusionOperator(eng, 1, 0.1, dcoef=[6.0])
+    slow = DiffusionOperator(eng, 1, 0.1, dcoef=[6.0], allow_fast=False)
+    a, b = eng.upload_packed(u0), eng.upload_packed(u0)
+    eng.adi_steps(fast, a, 5)
+    eng.adi_steps(slow, b, 5)
+    ha, hb = eng.download_packed(a), eng.download_packed(b)
+    assert rel_err(ha, hb) < 1e-13
+    assert abs(ha.sum() - u0.sum()) / u0.sum() < 1e-13           # zero-flux walls conserve the integral
+    assert ha.min() >= u0.min() and ha.max() <= u0.max()         # discrete maximum principle for r D = 0.3
