@@ -104,8 +104,8 @@ def main():
     from qpsim_amd import bench_workloads as W
 
     wl = W.build(args.workload, dev)
-    for _ in range(args.warmup):
-        wl.step()
+    if args.warmup > 0:
+        wl.run(args.warmup)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -115,8 +115,7 @@ def main():
 
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wl.step()
+    wl.run(args.steps)        # exactly `steps` time steps of the hot path, enqueued back to back
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     if world > 1:

@@ -158,14 +158,20 @@ int qp_axpy(int64_t n, double alpha, const double* x, double* y, void* stream);
  *   dcoef_host [nfield] diffusivities (HOST pointer; tables are built on the host at plan creation)
  *   bc_diag    [4] boundary diagonal terms of the left, right, up, down sides in 1/dx^2 units (see ex/ey above)
  *   bc_src     [4] boundary source terms of the same sides (see sx/sy above)
+ *   force_banded  0: when the far couplings between 64-cell chunks underflow fp64 significance (< 1e-22, true for
+ *              r*D <~ 1.5) the interface unknowns are solved as independent 2x2 systems inside the sweep kernels;
+ *              otherwise, or when force_banded != 0, a banded reduced solve runs between the sweeps.
+ *              qp_adi_rect_plan_decoupled(plan, dir) reports which one a direction uses (1 / 0).
  * The plan owns its device tables and work planes (hipMalloc at creation, the only allocating call).
  * qp_adi_rect_steps advances u [nfield][ny*nx] in place by `nsteps` consecutive diffusion steps; intermediate
  * fields are not materialised (steady-state traffic: one read + one write of the field per sweep).
  */
 typedef struct qp_adi_rect_plan qp_adi_rect_plan;
 int qp_adi_rect_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, const double* dcoef_host,
-                            const double* bc_diag, const double* bc_src, qp_adi_rect_plan** out);
+                            const double* bc_diag, const double* bc_src, int32_t force_banded,
+                            qp_adi_rect_plan** out);
 int qp_adi_rect_plan_destroy(qp_adi_rect_plan* plan);
+int qp_adi_rect_plan_decoupled(const qp_adi_rect_plan* plan, int32_t dir);
 int qp_adi_rect_steps(qp_adi_rect_plan* plan, double* u, int32_t nsteps, void* stream);
 
 #ifdef __cplusplus

@@ -24,6 +24,8 @@
 // Global accesses: lane <-> column, one 512 B row segment per wave instruction.  x-direction work needs
 // lane <-> row, so the tile goes through LDS (pitch 65 doubles: conflict-free both ways) at each change of
 // direction.  y-direction work happens entirely in registers (64 doubles per lane).
+#include <algorithm>
+#include <cmath>
 #include <vector>
 
 #include "qp_common.h"
@@ -32,6 +34,9 @@ namespace qp {
 
 constexpr int TS = 64;          // tile edge = chunk length
 constexpr int PITCH = TS + 1;   // LDS row pitch in doubles
+// far-corner weights of the reduced system below this (relative to its unit diagonal) are dropped: six orders of
+// magnitude under the fp64 rounding of the retained terms
+constexpr double kFarCouplingDrop = 1e-22;
 
 // table slots per (direction, field, chunk variant); each slot is TS doubles
 enum { T_W = 0, T_AWF, T_AWB, T_CM, T_C0, T_CP, T_SRC, T_G, T_H, T_NSLOT };
@@ -48,6 +53,8 @@ struct RectView {
   const double* lu[2];          // per dir: [nfield][5][2P]  (l1, l2, uinv, u1, u2)
   double* iface[2];             // per dir: [nfield][2P][nlines]   reduced right-hand sides
   double* z[2];                 // per dir: [nfield][2P][nlines]   reduced solutions (F_0, E_0, F_1, E_1, ...)
+  const double* icoef[2];       // per dir: [nfield][P][3]  (s, t, 1/(1 - s t)) of the interface between chunk p and p+1
+  int decoupled[2];             // per dir: far couplings underflow -> every interface is an independent 2 x 2 system
   double other_src[2][2];       // [dir][lo/hi]: a-less source of the faces normal to `dir` (x: sx_lo, sx_hi)
 };
 
@@ -156,6 +163,42 @@ __device__ __forceinline__ void store_cols(double* __restrict__ base, const Tile
     if (r < t.nr) p[(long)r * nx] = v[r];
 }
 
+// Values of the solved line just outside chunk p: gl = E_{p-1} (last unknown of the previous chunk),
+// gr = F_{p+1} (first unknown of the next chunk).
+//
+// The reduced system couples F_p, E_p to E_{p-1} and F_{p+1} with weights a g_p[0], a h_p[last] (O(1)) and
+// a g_p[last], a h_p[0] (the far corners of A_p^-1, which decay like rho^63 along the chunk).  When the plan found the
+// far weights below 1e-22 for every chunk (`decoupled`), dropping them perturbs the solution far below fp64 rounding and
+// each interface (E_p, F_{p+1}) becomes its own 2 x 2 system
+//      E - s F = y_p[last],   F - t E = y_{p+1}[0],     s = a h_p[last], t = a g_{p+1}[0]
+// which is solved here from the four reduced right-hand sides next to the chunk; otherwise the banded solve of
+// rect_reduced_kernel has produced z.
+template <int DIR>
+__device__ __forceinline__ void chunk_ghosts(const RectView& v, int b, int p, long line, bool on, double& gl,
+                                             double& gr) {
+  const int P = DIR == 0 ? v.d.px : v.d.py;
+  const long nlines = DIR == 0 ? v.d.ny : v.d.nx;
+  gl = 0.0;
+  gr = 0.0;
+  if (!on) return;
+  if (v.decoupled[DIR]) {
+    const double* ir = v.iface[DIR] + (long)b * 2 * P * nlines + line;
+    const double* ic = v.icoef[DIR] + (long)b * P * 3;
+    if (p > 0) {
+      const double yl = ir[(long)(2 * p - 1) * nlines], yf = ir[(long)(2 * p) * nlines];
+      gl = fma(ic[(p - 1) * 3], yf, yl) * ic[(p - 1) * 3 + 2];
+    }
+    if (p < P - 1) {
+      const double yl = ir[(long)(2 * p + 1) * nlines], yf = ir[(long)(2 * p + 2) * nlines];
+      gr = fma(ic[p * 3 + 1], yl, yf) * ic[p * 3 + 2];
+    }
+  } else {
+    const double* z = v.z[DIR] + (long)b * 2 * P * nlines + line;
+    if (p > 0) gl = z[(long)(2 * p - 1) * nlines];
+    if (p < P - 1) gr = z[(long)(2 * p + 2) * nlines];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // x-kernel: finish the x-solve, apply the explicit x-operator, eliminate along y.   buf: rhs1 -> rhs2 in place
 // ---------------------------------------------------------------------------------------------------------
@@ -172,9 +215,8 @@ __global__ void __launch_bounds__(64) rect_x_kernel(RectView v, double* __restri
   // lane = row from here
   const int row = t.j0 + lane;
   const bool row_on = lane < t.nr;
-  const double* zx = v.z[0] + (long)t.b * 2 * v.d.px * v.d.ny;
-  const double gl = (row_on && t.tx > 0) ? zx[(long)(2 * t.tx - 1) * v.d.ny + row] : 0.0;
-  const double gr = (row_on && t.tx < v.d.px - 1) ? zx[(long)(2 * t.tx + 2) * v.d.ny + row] : 0.0;
+  double gl, gr;
+  chunk_ghosts<0>(v, t.b, t.tx, row, row_on, gl, gr);
   const double* tx_tab = table_ptr(v, 0, t.b, chunk_variant(t.tx, v.d.px));
   e[0] = fma(a, gl, e[0]);
   e[TS - 1] = fma(a, gr, e[TS - 1]);   // gr != 0 only for full-length chunks
@@ -219,9 +261,7 @@ __global__ void __launch_bounds__(64) rect_y_kernel(RectView v, const double* sr
     if (col_on && t.ty > 0) gu = splane[(long)(t.j0 - 1) * v.d.nx + col];
     if (col_on && t.ty < v.d.py - 1) gd = splane[(long)(t.j0 + TS) * v.d.nx + col];
   } else {
-    const double* zy = v.z[1] + (long)t.b * 2 * v.d.py * v.d.nx;
-    if (col_on && t.ty > 0) gu = zy[(long)(2 * t.ty - 1) * v.d.nx + col];
-    if (col_on && t.ty < v.d.py - 1) gd = zy[(long)(2 * t.ty + 2) * v.d.nx + col];
+    chunk_ghosts<1>(v, t.b, t.ty, col, col_on, gu, gd);
     e[0] = fma(a, gu, e[0]);
     e[TS - 1] = fma(a, gd, e[TS - 1]);
     thomas64(e, ty_tab);
@@ -347,13 +387,20 @@ static void build_chunk_table(const DirSpec& s, double a, int p, double* tab, do
 }
 
 // banded LU (2 sub-, 2 super-diagonals, no pivoting: the matrix is strictly diagonally dominant)
-static void reduced_lu(const DirSpec& s, double a, double* lu /*[5][2P]*/) {
+// also fills icoef[P][3] (interface p | p+1) and returns the largest far-coupling weight of the reduced matrix
+static double reduced_lu(const DirSpec& s, double a, double* lu /*[5][2P]*/, double* icoef /*[P][3]*/) {
   const int m = 2 * s.P;
   std::vector<double> A((size_t)m * m, 0.0);
   std::vector<double> tab(TS * T_NSLOT);
+  std::vector<double> near_g(s.P), near_h(s.P);
+  double far = 0.0;
   for (int p = 0; p < s.P; ++p) {
     double ends[4];
     build_chunk_table(s, a, p, tab.data(), ends);
+    near_g[p] = a * ends[0];   // weight of E_{p-1} in the F_p equation
+    near_h[p] = a * ends[3];   // weight of F_{p+1} in the E_p equation
+    if (p > 0) far = std::max(far, std::fabs(a * ends[1]));
+    if (p < s.P - 1) far = std::max(far, std::fabs(a * ends[2]));
     const int f = 2 * p, e = 2 * p + 1;
     A[(size_t)f * m + f] = 1.0;
     A[(size_t)e * m + e] = 1.0;
@@ -380,6 +427,13 @@ static void reduced_lu(const DirSpec& s, double a, double* lu /*[5][2P]*/) {
     lu[3 * m + i] = i + 1 < m ? A[(size_t)i * m + i + 1] : 0.0;
     lu[4 * m + i] = i + 2 < m ? A[(size_t)i * m + i + 2] : 0.0;
   }
+  for (int p = 0; p < s.P; ++p) {
+    const double sc = near_h[p], tc = p + 1 < s.P ? near_g[p + 1] : 0.0;
+    icoef[p * 3] = sc;
+    icoef[p * 3 + 1] = tc;
+    icoef[p * 3 + 2] = 1.0 / (1.0 - sc * tc);
+  }
+  return far;
 }
 
 }  // namespace qp
@@ -389,6 +443,7 @@ struct qp_adi_rect_plan {
   double* d_alpha = nullptr;
   double* d_tab = nullptr;
   double* d_lu[2] = {nullptr, nullptr};
+  double* d_icoef[2] = {nullptr, nullptr};
   double* d_iface[2] = {nullptr, nullptr};
   double* d_z[2] = {nullptr, nullptr};
   double* d_work = nullptr;  // [nfield][ncell] carried right-hand side
@@ -403,6 +458,7 @@ int qp_adi_rect_plan_destroy(qp_adi_rect_plan* plan) {
   (void)hipFree(plan->d_tab);
   for (int d = 0; d < 2; ++d) {
     (void)hipFree(plan->d_lu[d]);
+    (void)hipFree(plan->d_icoef[d]);
     (void)hipFree(plan->d_iface[d]);
     (void)hipFree(plan->d_z[d]);
   }
@@ -412,7 +468,8 @@ int qp_adi_rect_plan_destroy(qp_adi_rect_plan* plan) {
 }
 
 int qp_adi_rect_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, const double* dcoef_host,
-                            const double* bc_diag, const double* bc_src, qp_adi_rect_plan** out) {
+                            const double* bc_diag, const double* bc_src, int32_t force_banded,
+                            qp_adi_rect_plan** out) {
   QP_REQUIRE(out != nullptr, "out is NULL");
   *out = nullptr;
   QP_REQUIRE(ny > 0 && nx > 0 && nfield > 0, "ny, nx, nfield must be positive");
@@ -433,8 +490,12 @@ int qp_adi_rect_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, co
 
   std::vector<double> alpha(nfield);
   std::vector<double> tab((size_t)2 * nfield * 4 * T_NSLOT * TS, 0.0);
-  std::vector<double> lu[2];
-  for (int d = 0; d < 2; ++d) lu[d].assign((size_t)nfield * 5 * 2 * spec[d].P, 0.0);
+  std::vector<double> lu[2], icoef[2];
+  double far[2] = {0.0, 0.0};
+  for (int d = 0; d < 2; ++d) {
+    lu[d].assign((size_t)nfield * 5 * 2 * spec[d].P, 0.0);
+    icoef[d].assign((size_t)nfield * spec[d].P * 3, 0.0);
+  }
   for (int b = 0; b < nfield; ++b) {
     const double a = r * dcoef_host[b];
     alpha[b] = a;
@@ -450,7 +511,7 @@ int qp_adi_rect_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, co
         double ends[4];
         build_chunk_table(spec[d], a, p, &tab[((((size_t)d * nfield + b) * 4 + var) * T_NSLOT) * TS], ends);
       }
-      reduced_lu(spec[d], a, &lu[d][(size_t)b * 5 * 2 * P]);
+      far[d] = std::max(far[d], reduced_lu(spec[d], a, &lu[d][(size_t)b * 5 * 2 * P], &icoef[d][(size_t)b * P * 3]));
     }
   }
   auto upload = [](const std::vector<double>& h, double** dptr) -> bool {
@@ -461,7 +522,7 @@ int qp_adi_rect_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, co
   for (int d = 0; d < 2 && ok; ++d) {
     const size_t nlines = d == 0 ? ny : nx;
     const size_t cnt = (size_t)nfield * 2 * spec[d].P * nlines;
-    ok = upload(lu[d], &plan->d_lu[d]) && hipMalloc((void**)&plan->d_iface[d], cnt * sizeof(double)) == hipSuccess &&
+    ok = upload(lu[d], &plan->d_lu[d]) && upload(icoef[d], &plan->d_icoef[d]) && hipMalloc((void**)&plan->d_iface[d], cnt * sizeof(double)) == hipSuccess &&
          hipMalloc((void**)&plan->d_z[d], cnt * sizeof(double)) == hipSuccess;
   }
   ok = ok && hipMalloc((void**)&plan->d_work, (size_t)nfield * plan->ncell * sizeof(double)) == hipSuccess;
@@ -475,11 +536,18 @@ int qp_adi_rect_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, co
   v.tab = plan->d_tab;
   for (int d = 0; d < 2; ++d) {
     v.lu[d] = plan->d_lu[d];
+    v.icoef[d] = plan->d_icoef[d];
+    v.decoupled[d] = (force_banded == 0 && far[d] < kFarCouplingDrop) ? 1 : 0;
     v.iface[d] = plan->d_iface[d];
     v.z[d] = plan->d_z[d];
   }
   *out = plan;
   return QP_OK;
+}
+
+int qp_adi_rect_plan_decoupled(const qp_adi_rect_plan* plan, int32_t dir) {
+  if (!plan || dir < 0 || dir > 1) return -1;
+  return plan->view.decoupled[dir];
 }
 
 int qp_adi_rect_steps(qp_adi_rect_plan* plan, double* u, int32_t nsteps, void* stream_) {
@@ -494,9 +562,9 @@ int qp_adi_rect_steps(qp_adi_rect_plan* plan, double* u, int32_t nsteps, void* s
   double* w = plan->d_work;
   hipLaunchKernelGGL(rect_y_kernel<0>, dim3(tiles), dim3(64), 0, stream, v, (const double*)u, w);
   for (int s = 0; s < nsteps; ++s) {
-    hipLaunchKernelGGL(rect_reduced_kernel, dim3(redx), dim3(64), 0, stream, v, 0);
+    if (!v.decoupled[0]) hipLaunchKernelGGL(rect_reduced_kernel, dim3(redx), dim3(64), 0, stream, v, 0);
     hipLaunchKernelGGL(rect_x_kernel, dim3(tiles), dim3(64), 0, stream, v, w);
-    hipLaunchKernelGGL(rect_reduced_kernel, dim3(redy), dim3(64), 0, stream, v, 1);
+    if (!v.decoupled[1]) hipLaunchKernelGGL(rect_reduced_kernel, dim3(redy), dim3(64), 0, stream, v, 1);
     if (s + 1 < nsteps)
       hipLaunchKernelGGL(rect_y_kernel<1>, dim3(tiles), dim3(64), 0, stream, v, (const double*)w, w);
     else

@@ -54,8 +54,9 @@ SIGNATURES = {
     "qp_absmax": (C.c_int, [c_dp, C.c_int64, c_dp, c_dp, c_dp]),
     "qp_axpy": (C.c_int, [C.c_int64, C.c_double, c_dp, c_dp, c_dp]),
     "qp_adi_rect_plan_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.POINTER(C.c_double),
-                                          C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                          C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32,
                                           C.POINTER(C.POINTER(RectPlan))]),
+    "qp_adi_rect_plan_decoupled": (C.c_int, [C.POINTER(RectPlan), C.c_int32]),
     "qp_adi_rect_plan_destroy": (C.c_int, [C.POINTER(RectPlan)]),
     "qp_adi_rect_steps": (C.c_int, [C.POINTER(RectPlan), c_dp, C.c_int32, c_dp]),
 }

@@ -46,12 +46,11 @@ class ADIWorkload:
                             "full rectangle, reflective walls, D=6 dt=0.1 dx=1")
         self._pending = 0
 
-    def step(self):
-        # steps are enqueued one by one; the fast path call advances one step and keeps the field materialised
-        self.eng.adi_steps(self.op, self.u, 1)
-
-    def run_steps(self, k: int):
+    def run(self, k: int):
+        """Advance exactly k diffusion steps (one library call; the field is materialised again at the end)."""
         self.eng.adi_steps(self.op, self.u, k)
+
+    run_steps = run
 
     def roofline(self, nrep: int) -> dict:
         """Average duration of one sweep kernel launch (HIP events on the launch stream) vs algorithmic bytes."""

@@ -176,14 +176,15 @@ def rect_side_terms(geom: CompiledGeometry):
 class RectPlan:
     """Owner of a ``qp_adi_rect_plan`` (device tables + work planes of the fast full-rectangle ADI path)."""
 
-    def __init__(self, lib, ny, nx, nfield, r, dcoef, bc_diag, bc_src):
+    def __init__(self, lib, ny, nx, nfield, r, dcoef, bc_diag, bc_src, force_banded: bool = False):
         self._lib = lib
         self._h = C.POINTER(_hip.RectPlan)()
         dc = (C.c_double * nfield)(*[float(v) for v in dcoef])
         bd = (C.c_double * 4)(*bc_diag)
         bs = (C.c_double * 4)(*bc_src)
-        _hip.check(lib.qp_adi_rect_plan_create(ny, nx, nfield, float(r), dc, bd, bs, C.byref(self._h)),
-                   "qp_adi_rect_plan_create")
+        _hip.check(lib.qp_adi_rect_plan_create(ny, nx, nfield, float(r), dc, bd, bs, int(bool(force_banded)),
+                                               C.byref(self._h)), "qp_adi_rect_plan_create")
+        self.decoupled = (bool(lib.qp_adi_rect_plan_decoupled(self._h, 0)), bool(lib.qp_adi_rect_plan_decoupled(self._h, 1)))
 
     @property
     def handle(self):
@@ -204,7 +205,8 @@ class RectPlan:
 class DiffusionOperator:
     """(I - r L_x), (I - r L_y) and friends for one time step size on a batch of fields."""
 
-    def __init__(self, engine: "Engine", nfield: int, dt: float, dcoef=None, dfield=None, allow_fast: bool = True):
+    def __init__(self, engine: "Engine", nfield: int, dt: float, dcoef=None, dfield=None, allow_fast: bool = True,
+                 force_banded: bool = False):
         torch = engine.torch
         self.engine = engine
         self.nfield = int(nfield)
@@ -224,7 +226,7 @@ class DiffusionOperator:
         if sides is not None and self.dt > 0.0:
             with torch.cuda.device(engine.device):
                 self.rect = RectPlan(engine.lib, g.ny, g.nx, self.nfield, self.r, np.asarray(dcoef, dtype=float),
-                                     sides[0], sides[1])
+                                     sides[0], sides[1], force_banded=force_banded)
 
 
 class Engine:

@@ -344,14 +344,26 @@ def test_rect_fast_path_matches_oracle_adi_and_general_kernels(O, ny, nx):
     Dc = [6.0, 0.35, 0.0, 40.0]
     u0 = rng.random((len(Dc), ny * nx))
     fast = DiffusionOperator(eng, len(Dc), dt, dcoef=Dc)
+    banded = DiffusionOperator(eng, len(Dc), dt, dcoef=Dc, force_banded=True)
     slow = DiffusionOperator(eng, len(Dc), dt, dcoef=Dc, allow_fast=False)
-    assert fast.rect is not None and slow.rect is None
+    assert fast.rect is not None and slow.rect is None and banded.rect.decoupled == (False, False)
+    # D = 40 (r D = 2.7) keeps couplings between 64-cell chunks above the drop threshold: banded reduced solve
+    if max(ny, nx) > 64:
+        assert fast.rect.decoupled != (True, True)
+    mild = DiffusionOperator(eng, 2, dt, dcoef=Dc[:2])
+    assert mild.rect.decoupled == (True, True)
     for nsteps in (1, 3):
         a = eng.upload_packed(u0)
         b = eng.upload_packed(u0)
+        c = eng.upload_packed(u0)
+        d = eng.upload_packed(u0[:2])
         eng.adi_steps(fast, a, nsteps)
         eng.adi_steps(slow, b, nsteps)
+        eng.adi_steps(banded, c, nsteps)
+        eng.adi_steps(mild, d, nsteps)
         ha, hb = eng.download_packed(a), eng.download_packed(b)
+        assert rel_err(eng.download_packed(c), ha) < 2e-13
+        assert rel_err(eng.download_packed(d), eng.download_packed(c)[:2]) < 2e-13
         for k, D in enumerate(Dc):
             st = O.ADIStepper(ops, D, dt)
             want = u0[k].copy()
