@@ -351,7 +351,9 @@ def test_rect_fast_path_matches_oracle_adi_and_general_kernels(O, ny, nx):
     if max(ny, nx) > 64:
         assert fast.rect.decoupled != (True, True)
     mild = DiffusionOperator(eng, 2, dt, dcoef=Dc[:2])
-    assert mild.rect.decoupled == (True, True)
+    # a short remainder chunk (n % 64 small) keeps a visible coupling through it -> that direction stays banded
+    expect = tuple(n <= 64 or n % 64 == 0 or n % 64 >= 48 for n in (nx, ny))
+    assert mild.rect.decoupled == expect
     for nsteps in (1, 3):
         a = eng.upload_packed(u0)
         b = eng.upload_packed(u0)
