@@ -33,7 +33,6 @@
 namespace qp {
 
 constexpr int TS = 64;          // tile edge = chunk length
-constexpr int PITCH = TS + 1;   // LDS row pitch in doubles
 // far-corner weights of the reduced system below this (relative to its unit diagonal) are dropped: six orders of
 // magnitude under the fp64 rounding of the retained terms
 constexpr double kFarCouplingDrop = 1e-22;
@@ -63,12 +62,24 @@ __device__ __forceinline__ int chunk_variant(int p, int P) {
   return (p == 0 ? 1 : 0) | (p == P - 1 ? 2 : 0);
 }
 
-__device__ __forceinline__ const double* table_ptr(const RectView& v, int dir, int b, int variant) {
-  return v.tab + ((((long)dir * v.d.nfield + b) * 4 + variant) * T_NSLOT) * TS;
+// Tables are written once at plan creation and never by a kernel: read them through the constant address space so
+// that wave-uniform accesses become scalar loads (s_load) and the values feed the FMAs straight from SGPRs.
+typedef const double __attribute__((address_space(4))) * ctab_t;
+
+__device__ __forceinline__ ctab_t as_const(const double* p) {
+  // the address is wave-uniform by construction (kernel arguments and blockIdx only): say so explicitly
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return (ctab_t)(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ ctab_t table_ptr(const RectView& v, int dir, int b, int variant) {
+  return as_const(v.tab + ((((long)dir * v.d.nfield + b) * 4 + variant) * T_NSLOT) * TS);
 }
 
 // Thomas solve of one chunk held in registers; padded entries (k >= chunk length) carry w = 1, aw = 0.
-__device__ __forceinline__ void thomas64(double (&e)[TS], const double* __restrict__ t) {
+__device__ __forceinline__ void thomas64(double (&e)[TS], ctab_t t) {
   double dp = 0.0;
 #pragma unroll
   for (int k = 0; k < TS; ++k) {
@@ -84,21 +95,19 @@ __device__ __forceinline__ void thomas64(double (&e)[TS], const double* __restri
 }
 
 // e <- (I + a L) e + a s along the chunk, with neighbour values gl / gr beyond its ends, plus `extra` on valid cells.
-__device__ __forceinline__ void explicit64(double (&e)[TS], double gl, double gr, const double* __restrict__ t,
-                                           double extra, int len) {
+__device__ __forceinline__ void explicit64(double (&e)[TS], double gl, double gr, ctab_t t, double extra) {
   double prev = gl;
 #pragma unroll
   for (int k = 0; k < TS; ++k) {
     const double cur = e[k];
     const double nxt = (k + 1 < TS) ? e[k + 1] : gr;
-    double out = fma(t[T_CM * TS + k], prev, fma(t[T_CP * TS + k], nxt, fma(t[T_C0 * TS + k], cur, t[T_SRC * TS + k])));
-    out += (k < len) ? extra : 0.0;
-    e[k] = out;
+    // `extra` also lands on padded cells (k >= chunk length); those are never stored and meet zero weights in dots64
+    e[k] = fma(t[T_CM * TS + k], prev, fma(t[T_CP * TS + k], nxt, fma(t[T_C0 * TS + k], cur, t[T_SRC * TS + k] + extra)));
     prev = cur;
   }
 }
 
-__device__ __forceinline__ void dots64(const double (&e)[TS], const double* __restrict__ t, double& yf, double& yl) {
+__device__ __forceinline__ void dots64(const double (&e)[TS], ctab_t t, double& yf, double& yl) {
   double a0 = 0.0, a1 = 0.0;
 #pragma unroll
   for (int k = 0; k < TS; ++k) {
@@ -109,23 +118,40 @@ __device__ __forceinline__ void dots64(const double (&e)[TS], const double* __re
   yl = a1;
 }
 
-// registers (lane = column, index = row)  ->  registers (lane = row, index = column), through LDS
-__device__ __forceinline__ void transpose_c2r(double (&v)[TS], double* lds, int lane) {
-#pragma unroll
-  for (int r = 0; r < TS; ++r) lds[r * PITCH + lane] = v[r];
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < TS; ++k) v[k] = lds[lane * PITCH + k];
-  __syncthreads();
+// In-place transpose of the 64 x 64 tile distributed as v[j] on lane i  ->  v[i] on lane j (its own inverse:
+// lane = column / index = row  <->  lane = row / index = column).  Viewed as 2 x 2 blocks of 32 x 32:
+//   1. v_permlane32_swap exchanges the off-diagonal blocks between the half-waves (registers 0..31 of lanes 32..63
+//      <-> registers 32..63 of lanes 0..31), no memory involved;
+//   2. every block is then transposed inside its own half-wave through a 32 x 33 LDS block, registers 0..31 first,
+//      32..63 second, so only 2 x 32 x 33 doubles (16.5 KiB per wave instead of 33 KiB) are live and no lane-dependent
+//      register index appears.  Pitch 33 keeps the column-wise writes and row-wise reads conflict-free.
+constexpr int HB = 32;
+constexpr int HP = HB + 1;
+constexpr int LDS_DOUBLES = 2 * HB * HP;
+
+__device__ __forceinline__ void swap_half_waves(double& lo_reg, double& hi_reg) {
+  // lanes 32..63 of lo_reg <-> lanes 0..31 of hi_reg
+  const unsigned long long a = __double_as_longlong(lo_reg), b = __double_as_longlong(hi_reg);
+  const auto r0 = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
+  const auto r1 = __builtin_amdgcn_permlane32_swap((unsigned)(a >> 32), (unsigned)(b >> 32), false, false);
+  lo_reg = __longlong_as_double(((unsigned long long)r1[0] << 32) | r0[0]);
+  hi_reg = __longlong_as_double(((unsigned long long)r1[1] << 32) | r0[1]);
 }
 
-__device__ __forceinline__ void transpose_r2c(double (&v)[TS], double* lds, int lane) {
+__device__ __forceinline__ void transpose64(double (&v)[TS], double* lds, int lane) {
+  const int l = lane & 31;
+  double* blk = lds + (lane >> 5) * (HB * HP);
 #pragma unroll
-  for (int k = 0; k < TS; ++k) lds[lane * PITCH + k] = v[k];
-  __syncthreads();
+  for (int k = 0; k < HB; ++k) swap_half_waves(v[k], v[HB + k]);
 #pragma unroll
-  for (int r = 0; r < TS; ++r) v[r] = lds[r * PITCH + lane];
-  __syncthreads();
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int k = 0; k < HB; ++k) blk[k * HP + l] = v[half * HB + k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < HB; ++k) v[half * HB + k] = blk[l * HP + k];
+    __syncthreads();
+  }
 }
 
 struct TileCoord {
@@ -148,19 +174,28 @@ __device__ __forceinline__ TileCoord tile_coord(const RectDims& d) {
 
 __device__ __forceinline__ void load_cols(const double* __restrict__ base, const TileCoord& t, int nx, int lane,
                                           double (&v)[TS]) {
-  const bool on = lane < t.nc;
   const double* p = base + (long)t.j0 * nx + t.i0 + lane;
+  if (t.nr == TS && t.nc == TS) {      // interior tile (wave-uniform test): 64 unconditional row-segment loads
 #pragma unroll
-  for (int r = 0; r < TS; ++r) v[r] = (on && r < t.nr) ? p[(long)r * nx] : 0.0;
+    for (int r = 0; r < TS; ++r) v[r] = p[(long)r * nx];
+  } else {
+    const bool on = lane < t.nc;
+#pragma unroll
+    for (int r = 0; r < TS; ++r) v[r] = (on && r < t.nr) ? p[(long)r * nx] : 0.0;
+  }
 }
 
 __device__ __forceinline__ void store_cols(double* __restrict__ base, const TileCoord& t, int nx, int lane,
                                            const double (&v)[TS]) {
-  if (lane >= t.nc) return;
   double* p = base + (long)t.j0 * nx + t.i0 + lane;
+  if (t.nr == TS && t.nc == TS) {
 #pragma unroll
-  for (int r = 0; r < TS; ++r)
-    if (r < t.nr) p[(long)r * nx] = v[r];
+    for (int r = 0; r < TS; ++r) p[(long)r * nx] = v[r];
+  } else if (lane < t.nc) {
+#pragma unroll
+    for (int r = 0; r < TS; ++r)
+      if (r < t.nr) p[(long)r * nx] = v[r];
+  }
 }
 
 // Values of the solved line just outside chunk p: gl = E_{p-1} (last unknown of the previous chunk),
@@ -183,7 +218,7 @@ __device__ __forceinline__ void chunk_ghosts(const RectView& v, int b, int p, lo
   if (!on) return;
   if (v.decoupled[DIR]) {
     const double* ir = v.iface[DIR] + (long)b * 2 * P * nlines + line;
-    const double* ic = v.icoef[DIR] + (long)b * P * 3;
+    const ctab_t ic = as_const(v.icoef[DIR] + (long)b * P * 3);
     if (p > 0) {
       const double yl = ir[(long)(2 * p - 1) * nlines], yf = ir[(long)(2 * p) * nlines];
       gl = fma(ic[(p - 1) * 3], yf, yl) * ic[(p - 1) * 3 + 2];
@@ -203,29 +238,29 @@ __device__ __forceinline__ void chunk_ghosts(const RectView& v, int b, int p, lo
 // x-kernel: finish the x-solve, apply the explicit x-operator, eliminate along y.   buf: rhs1 -> rhs2 in place
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) rect_x_kernel(RectView v, double* __restrict__ buf) {
-  __shared__ double lds[TS * PITCH];
+  __shared__ double lds[LDS_DOUBLES];
   const int lane = threadIdx.x;
   const TileCoord t = tile_coord(v.d);
   const long ncell = (long)v.d.ny * v.d.nx;
   double* plane = buf + (long)t.b * ncell;
-  const double a = v.alpha[t.b];
+  const double a = as_const(v.alpha)[t.b];
   double e[TS];
   load_cols(plane, t, v.d.nx, lane, e);
-  transpose_c2r(e, lds, lane);
+  transpose64(e, lds, lane);
   // lane = row from here
   const int row = t.j0 + lane;
   const bool row_on = lane < t.nr;
   double gl, gr;
   chunk_ghosts<0>(v, t.b, t.tx, row, row_on, gl, gr);
-  const double* tx_tab = table_ptr(v, 0, t.b, chunk_variant(t.tx, v.d.px));
+  const ctab_t tx_tab = table_ptr(v, 0, t.b, chunk_variant(t.tx, v.d.px));
   e[0] = fma(a, gl, e[0]);
   e[TS - 1] = fma(a, gr, e[TS - 1]);   // gr != 0 only for full-length chunks
   thomas64(e, tx_tab);
   double srow = 0.0;                   // sources of the y-faces (up/down) belong to rows 0 and ny-1
   if (row == 0) srow += a * v.other_src[1][0];
   if (row == v.d.ny - 1) srow += a * v.other_src[1][1];
-  explicit64(e, gl, gr, tx_tab, row_on ? srow : 0.0, t.nc);
-  transpose_r2c(e, lds, lane);
+  explicit64(e, gl, gr, tx_tab, row_on ? srow : 0.0);
+  transpose64(e, lds, lane);
   // lane = column again
   store_cols(plane, t, v.d.nx, lane, e);
   double yf, yl;
@@ -244,16 +279,16 @@ __global__ void __launch_bounds__(64) rect_x_kernel(RectView v, double* __restri
 // ---------------------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ void __launch_bounds__(64) rect_y_kernel(RectView v, const double* src, double* dst) {  // src may alias dst
-  __shared__ double lds[TS * PITCH];
+  __shared__ double lds[LDS_DOUBLES];
   const int lane = threadIdx.x;
   const TileCoord t = tile_coord(v.d);
   const long ncell = (long)v.d.ny * v.d.nx;
   const double* splane = src + (long)t.b * ncell;
   double* dplane = dst + (long)t.b * ncell;
-  const double a = v.alpha[t.b];
+  const double a = as_const(v.alpha)[t.b];
   const int col = t.i0 + lane;
   const bool col_on = lane < t.nc;
-  const double* ty_tab = table_ptr(v, 1, t.b, chunk_variant(t.ty, v.d.py));
+  const ctab_t ty_tab = table_ptr(v, 1, t.b, chunk_variant(t.ty, v.d.py));
   double e[TS];
   load_cols(splane, t, v.d.nx, lane, e);
   double gu = 0.0, gd = 0.0;           // values of the field just above / below the tile
@@ -273,9 +308,9 @@ __global__ void __launch_bounds__(64) rect_y_kernel(RectView v, const double* sr
   double scol = 0.0;                   // sources of the x-faces (left/right) belong to columns 0 and nx-1
   if (col == 0) scol += a * v.other_src[0][0];
   if (col == v.d.nx - 1) scol += a * v.other_src[0][1];
-  explicit64(e, gu, gd, ty_tab, col_on ? scol : 0.0, t.nr);
+  explicit64(e, gu, gd, ty_tab, col_on ? scol : 0.0);
   store_cols(dplane, t, v.d.nx, lane, e);
-  transpose_c2r(e, lds, lane);
+  transpose64(e, lds, lane);
   double yf, yl;
   dots64(e, table_ptr(v, 0, t.b, chunk_variant(t.tx, v.d.px)), yf, yl);
   if (lane < t.nr) {
