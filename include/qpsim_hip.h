@@ -105,6 +105,12 @@ typedef struct qp_collision_tables {
   const int32_t* idx_sum;  /* [ne][ne] phonon bin of Ei+Ej */
   const int8_t* sign;      /* [ne][ne] sign(Ei-Ej) */
   const int32_t* cls;      /* [ncell] gap class per cell, or NULL when nclass == 1 */
+  /* Optional structure hint (both or neither).  On the reference's uniform energy grid idx_diff[i][j] = diag_bin[|i-j|]
+   * and idx_sum[i][j] = anti_bin[i+j]; when the host has verified that AND that no phonon bin is shared between a
+   * diagonal and an anti-diagonal, passing the two arrays selects the register-resident kernel (nclass == 1, ne <= 16;
+   * ph_scratch unused).  NULL selects the generic table-driven kernel. */
+  const int32_t* diag_bin; /* [ne] or NULL */
+  const int32_t* anti_bin; /* [2*ne-1] or NULL */
 } qp_collision_tables;
 
 /*

@@ -126,6 +126,10 @@ __global__ void __launch_bounds__(256) collision_generic_kernel(CollView t, cons
   }
 }
 
+bool collision_fast_dispatch(int ne, const double* kr0, const double* ks0, const double* rho, const int* diag_bin,
+                             const int* anti_bin, const uint8_t* flags, long ncell, const double* sin_, double* sout,
+                             double* ph, double dE, double dt, int en_r, int en_s, int upd, hipStream_t stream);
+
 }  // namespace qp
 
 extern "C" int qp_collision_step(const qp_collision_tables* t, const uint8_t* flags, int64_t ncell,
@@ -139,8 +143,15 @@ extern "C" int qp_collision_step(const qp_collision_tables* t, const uint8_t* fl
   QP_REQUIRE(flags && state_in && state_out && phonon, "flags, state_in, state_out, phonon must be non-NULL");
   QP_REQUIRE(state_in != state_out, "state_in and state_out must not alias");
   QP_REQUIRE(ncell > 0, "ncell must be positive");
-  QP_REQUIRE(!(update_phonons && (enable_recombination || enable_scattering)) || ph_scratch,
-             "ph_scratch is required when phonons are updated");
+  const bool fast_ok = t->diag_bin && t->anti_bin && t->nclass == 1 && t->ne >= 2 && t->ne <= 16;
+  QP_REQUIRE(!(update_phonons && (enable_recombination || enable_scattering)) || ph_scratch || fast_ok,
+             "ph_scratch is required when phonons are updated by the generic kernel");
+  QP_REQUIRE((t->diag_bin == nullptr) == (t->anti_bin == nullptr), "diag_bin and anti_bin come together");
+  if (t->diag_bin && t->nclass == 1 &&
+      qp::collision_fast_dispatch(t->ne, t->kr0, t->ks0, t->rho, t->diag_bin, t->anti_bin, flags, (long)ncell, state_in,
+                                  state_out, phonon, dE, dt, enable_recombination, enable_scattering, update_phonons,
+                                  (hipStream_t)stream))
+    return qp::check_launch("qp_collision_step(fast)");
   qp::CollView v{t->ne, t->nw, t->nclass, t->kr0, t->ks0, t->rho, t->idx_diff, t->idx_sum, t->sign, t->cls};
   const unsigned blocks = (unsigned)((ncell + 255) / 256);
   hipLaunchKernelGGL(qp::collision_generic_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, flags,

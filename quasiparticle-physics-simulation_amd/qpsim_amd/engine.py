@@ -173,6 +173,26 @@ def rect_side_terms(geom: CompiledGeometry):
     return [xs[0], xs[1], ys[0], ys[1]], [xs[2], xs[3], ys[2], ys[3]]
 
 
+def structured_bin_maps(idx_diff, idx_sum, sign):
+    """(diag_bin[NE], anti_bin[2NE-1]) if idx_diff[i][j] depends only on |i-j|, idx_sum[i][j] only on i+j, sign is
+    sign(i-j), the tables are symmetric in that sense and no phonon bin is fed by both a diagonal (k >= 1) and an
+    anti-diagonal; None otherwise (merged bins, e.g. when 2 E_min / dE is an integer)."""
+    idx_diff, idx_sum, sign = np.asarray(idx_diff), np.asarray(idx_sum), np.asarray(sign)
+    ne = idx_diff.shape[0]
+    if ne < 2:
+        return None
+    i, j = np.indices((ne, ne))
+    diag = idx_diff[np.arange(ne), 0]            # k = i - 0
+    anti = np.concatenate([idx_sum[0, :], idx_sum[1:, -1]])   # m = 0..2ne-2
+    if not (np.array_equal(idx_diff, diag[np.abs(i - j)]) and np.array_equal(idx_sum, anti[i + j])
+            and np.array_equal(sign, np.sign(i - j))):
+        return None
+    used = np.concatenate([diag[1:], anti])
+    if np.unique(used).size != used.size:
+        return None
+    return diag.astype(np.int32), anti.astype(np.int32)
+
+
 class RectPlan:
     """Owner of a ``qp_adi_rect_plan`` (device tables + work planes of the fast full-rectangle ADI path)."""
 
@@ -350,7 +370,7 @@ class Engine:
         return float(self._red_vals[0].item())
 
     # -- collisions, generation, reductions -------------------------------------------------------------------
-    def make_collision_tables(self, kr0, ks0, rho, idx_diff, idx_sum, sign, cls_packed=None):
+    def make_collision_tables(self, kr0, ks0, rho, idx_diff, idx_sum, sign, cls_packed=None, allow_fast=True):
         """Upload per-gap-class tables ([C,NE,NE], [C,NE]) and maps; returns an opaque handle."""
         torch = self.torch
         up = lambda a, dt: None if a is None else torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=self.device)  # noqa: E731
@@ -368,12 +388,19 @@ class Engine:
             full[self.mask_flat] = np.asarray(cls_packed, dtype=np.int32)
             h["cls"] = up(full, np.int32)
         h["nw"] = nw
+        h["diag_bin"] = h["anti_bin"] = None
+        structure = None if (nclass > 1 or not allow_fast) else structured_bin_maps(idx_diff, idx_sum, sign)
+        if structure is not None:
+            h["diag_bin"], h["anti_bin"] = up(structure[0], np.int32), up(structure[1], np.int32)
+        h["fast"] = structure is not None and 2 <= ne <= 16
         h["struct"] = _hip.CollisionTables(ne, nw, nclass, _ptr(h["kr0"]), _ptr(h["ks0"]), _ptr(h["rho"]),
-                                           _ptr(h["idx_diff"]), _ptr(h["idx_sum"]), _ptr(h["sign"]), _ptr(h["cls"]))
+                                           _ptr(h["idx_diff"]), _ptr(h["idx_sum"]), _ptr(h["sign"]), _ptr(h["cls"]),
+                                           _ptr(h["diag_bin"]), _ptr(h["anti_bin"]))
         return h
 
     def collide(self, tables, state, state_out, phonon, dE, dt, en_r, en_s, update_phonons):
-        acc = self.scratch("coll_acc", 2 * tables["nw"] * self.ncell) if (update_phonons and (en_r or en_s)) else None
+        need_acc = update_phonons and (en_r or en_s) and not tables["fast"]
+        acc = self.scratch("coll_acc", 2 * tables["nw"] * self.ncell) if need_acc else None
         _hip.check(self.lib.qp_collision_step(C.byref(tables["struct"]), _ptr(self.d_flags), self.ncell, _ptr(state),
                                               _ptr(state_out), _ptr(phonon), _ptr(acc), float(dE), float(dt),
                                               int(bool(en_r)), int(bool(en_s)), int(bool(update_phonons)), self.stream),

@@ -395,3 +395,51 @@ def test_rect_fast_path_large_reflective_conserves_mass_and_matches_general():
     assert rel_err(ha, hb) < 1e-13
     assert abs(ha.sum() - u0.sum()) / u0.sum() < 1e-13           # zero-flux walls conserve the integral
     assert ha.min() >= u0.min() and ha.max() <= u0.max()         # discrete maximum principle for r D = 0.3
+
+
+@pytest.mark.parametrize("ne,fmax", [(2, 3.0), (5, 3.0), (8, 4.0), (12, 3.0), (16, 10.0)])
+@pytest.mark.parametrize("en_r,en_s,upd", [(True, True, True), (True, False, True), (False, True, True), (True, True, False)])
+def test_fast_collision_kernel_matches_generic_and_oracle(O, ne, fmax, en_r, en_s, upd):
+    """Register-resident diagonal kernel (uniform tables, NE <= 16) vs the generic kernel and the oracle."""
+    from qpsim_amd import tables as T
+    from qpsim_amd.engine import CompiledGeometry, Engine, link_flags, structured_bin_maps
+    rng = np.random.default_rng(ne * 7 + int(en_r) + 2 * int(en_s))
+    mask = rng.random((9, 31)) > 0.2
+    z = np.zeros(mask.shape)
+    eng = Engine(CompiledGeometry(mask, 1.0, link_flags(mask), z, z, z, z))
+    n = int(mask.sum())
+    gap, gamma = 180.0, 0.1
+    E, dE = T.build_energy_grid(gap, 1.0, fmax, ne)
+    om, idx_d, idx_s, sg = T.build_phonon_frequency_map(E)
+    assert structured_bin_maps(idx_d, idx_s, sg) is not None
+    rho = T.dynes_density_of_states(E, gap, gamma)
+    kr, ks = T.recombination_kernel_base(E, gap, 500.0, 1.2), T.scattering_kernel_base(E, gap, 400.0, 1.2)
+    state = rng.random((ne, n)) * rho[:, None] * rng.choice([1e-5, 1e-2, 0.5, 0.95], size=n)[None, :]
+    ph = T.thermal_phonon_occupation(om, 0.3)[:, None] * (0.5 + rng.random((om.size, n)))
+    outs = []
+    for fast in (True, False):
+        tab = eng.make_collision_tables(kr[None], ks[None], rho[None], idx_d, idx_s, sg, allow_fast=fast)
+        assert tab["fast"] == fast
+        s_in, p_dev = eng.upload_packed(state), eng.upload_packed(ph)
+        s_out = eng.empty(ne, eng.ncell)
+        eng.collide(tab, s_in, s_out, p_dev, dE, 0.37, en_r, en_s, upd)
+        outs.append((eng.download_packed(s_out), eng.download_packed(p_dev), s_out.cpu().numpy()))
+    assert rel_err(outs[0][0], outs[1][0]) < 1e-12 and rel_err(outs[0][1], outs[1][1]) < 1e-11
+    assert np.all(outs[0][2][:, ~mask.reshape(-1)] == 0.0)
+    tables = {"rho": rho[None], "Kr0": kr[None] if en_r else None, "Ks0": ks[None] if en_s else None,
+              "cls": np.zeros(n, dtype=int), "idx_diff": idx_d, "idx_sum": idx_s, "sign": sg, "dE": dE}
+    s_ref, p_ref = state.copy(), ph.copy()
+    O.collision_step(s_ref, p_ref, tables, 0.37, en_r=en_r, en_s=en_s, update_phonons=upd)
+    assert rel_err(outs[0][0], s_ref) < 1e-12 and rel_err(outs[0][1], p_ref) < 1e-11
+
+
+def test_merged_phonon_bins_fall_back_to_generic_kernel():
+    from qpsim_amd import tables as T
+    from qpsim_amd.engine import structured_bin_maps
+    E, _ = T.build_energy_grid(180.0, 1.0, 10.0, 18)      # 2 E_min / dE = 4: sums and differences share bins
+    om, idx_d, idx_s, sg = T.build_phonon_frequency_map(E)
+    assert om.size < 18 + 35 and structured_bin_maps(idx_d, idx_s, sg) is None
+    E, _ = T.build_energy_grid(180.0, 1.0, 3.0, 12)
+    om, idx_d, idx_s, sg = T.build_phonon_frequency_map(E)
+    d, a = structured_bin_maps(idx_d, idx_s, sg)
+    assert om.size == 35 and d.size == 12 and a.size == 23
