@@ -138,6 +138,8 @@ def main():
         "roofline": roof,
         "hbm_frac_of_step": (wl.bytes_per_step * args.steps / elapsed / 1e9) / HBM_PEAK_GBS,
     }
+    if hasattr(wl, "coll_bytes_per_call"):
+        result["pixel_steps_per_s"] = wl.N * wl.N * world * args.steps / elapsed
     if rank == 0:
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, args.workload)

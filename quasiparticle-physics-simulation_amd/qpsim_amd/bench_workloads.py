@@ -77,8 +77,96 @@ class ADIWorkload:
                 "note": "launch time = (event time of k-step calls) / (2k+1 sweep launches); includes the reduced-system kernels"}
 
 
+class CoupledWorkload:
+    """Energy-resolved hot loop: external generation off, Strang C(dt/2) D(dt) C(dt/2), Pauli guard every step.
+
+    SURVEY 8(d) parameters: gap 180 ueV, factors 1-3, NE = 12, tau_0 = 440 ns, Tc = 1.2 K, Tb = 0.1 K, gamma = 0.
+    c2: N = 1024, recombination only, phonons frozen.  c3: N = 4096, recombination + scattering, dynamic phonons.
+    """
+
+    def __init__(self, N, device, *, ne=12, recombination=True, scattering=True, dynamic_phonons=True, label=""):
+        self.N, self.nfield, self.ne = N, ne, ne
+        self.eng = eng = _rect_engine(N, device)
+        torch = eng.torch
+        gap, D0, dt = 180.0, 6.0, 0.1
+        self.dt = dt
+        E, dE = T.build_energy_grid(gap, 1.0, 3.0, ne)
+        self.dE = dE
+        om, idx_d, idx_s, sg = T.build_phonon_frequency_map(E)
+        self.nw = om.size
+        rho = T.dynes_density_of_states(E, gap, 0.0)
+        kr = T.recombination_kernel_base(E, gap, 440.0, 1.2)[None] if recombination else None
+        ks = T.scattering_kernel_base(E, gap, 440.0, 1.2)[None] if scattering else None
+        self.tab = eng.make_collision_tables(kr, ks, rho[None], idx_d, idx_s, sg)
+        self.en_r, self.en_s, self.upd = recombination, scattering, dynamic_phonons
+        w = rho / (np.sum(rho) * dE)
+        init = 1e-4 * (1.0 + np.random.default_rng(0).random(N * N))
+        self.state = torch.as_tensor(w[:, None] * init[None, :], device=eng.device)
+        self.alt = torch.empty_like(self.state)
+        nph = T.thermal_phonon_occupation(om, 0.1)
+        self.phonon = torch.as_tensor(np.repeat(nph[:, None], N * N, axis=1), device=eng.device)
+        self.op = DiffusionOperator(eng, ne, dt, dcoef=T.diffusion_coefficients(E, gap, D0))
+        self.grid = [N, N]
+        self.cell_updates_per_step = float(N) * N * ne
+        planes_rw = (ne + self.nw) + (ne + (self.nw if dynamic_phonons else 0))
+        self.coll_bytes_per_call = 8.0 * planes_rw * N * N
+        self.bytes_per_step = 48.0 * self.cell_updates_per_step + 2 * self.coll_bytes_per_call
+        self.path = ("rect-tiled ADI + " + ("diagonal register collision kernel" if self.tab["fast"] else "generic collision kernel"))
+        self.description = (f"{label}{N}x{N} fp64, NE={ne}, Nw={self.nw}: Strang C(dt/2) D(dt) C(dt/2) + Pauli guard per step; "
+                            f"recombination={'on' if recombination else 'off'}, scattering={'on' if scattering else 'off'}, "
+                            f"phonons {'dynamic' if dynamic_phonons else 'frozen'}; reflective walls, D0=6 dt=0.1 dx=1")
+        self.max_occ = 0.0
+
+    def _collide(self, dtc):
+        self.eng.collide(self.tab, self.state, self.alt, self.phonon, self.dE, dtc, self.en_r, self.en_s, self.upd)
+        self.state, self.alt = self.alt, self.state
+
+    def run(self, k: int):
+        for _ in range(k):
+            self._collide(0.5 * self.dt)
+            self.eng.adi_steps(self.op, self.state, 1)
+            self._collide(0.5 * self.dt)
+            mx, _, forb = self.eng.pauli_stats(self.state, self.tab, 1e-18)   # host reads it back, as the reference does
+            if forb is not None or mx > 1.0:
+                raise ValueError("Pauli guard tripped in the benchmark state")
+            self.max_occ = max(self.max_occ, mx)
+
+    def roofline(self, nrep: int) -> dict:
+        """Dominant kernel = the collision update (two calls per step): HIP-event time per call vs its plane traffic."""
+        torch = self.eng.torch
+        dev = self.eng.device
+        self._collide(0.5 * self.dt)
+        torch.cuda.synchronize(dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream(dev))
+        for _ in range(nrep):
+            self._collide(0.5 * self.dt)
+        ev1.record(torch.cuda.current_stream(dev))
+        torch.cuda.synchronize(dev)
+        per_call = ev0.elapsed_time(ev1) * 1e-3 / nrep
+        achieved = self.coll_bytes_per_call / per_call / 1e9
+        pairs = self.ne * self.ne
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "kernel": "collision_diag_kernel" if self.tab["fast"] else "collision_generic_kernel",
+                "bytes_per_launch": self.coll_bytes_per_call, "avg_launch_us": per_call * 1e6,
+                "pixel_updates_per_s": self.N * self.N / per_call,
+                "note": f"16*(NE+Nw) B per pixel when phonons are dynamic; ~26*NE^2 = {26 * pairs} flop per pixel-update"}
+
+
 def build(name: str, device):
     m = re.fullmatch(r"adi(\d+)", name)
     if m:
         return ADIWorkload(int(m.group(1)), device)
+    m = re.fullmatch(r"adi(\d+)x(\d+)", name)
+    if m:   # adi<N>x<F>: F independent fields of N x N (ensemble batch)
+        return ADIWorkload(int(m.group(1)), device, nfield=int(m.group(2)))
+    if name == "c2":
+        return CoupledWorkload(1024, device, recombination=True, scattering=False, dynamic_phonons=False,
+                               label="BASELINE configs[1]: ")
+    if name == "c3":
+        return CoupledWorkload(4096, device, recombination=True, scattering=True, dynamic_phonons=True,
+                               label="BASELINE configs[2]: ")
+    m = re.fullmatch(r"coupled(\d+)", name)
+    if m:
+        return CoupledWorkload(int(m.group(1)), device)
     raise ValueError(f"unknown workload '{name}'")

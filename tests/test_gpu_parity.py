@@ -430,7 +430,8 @@ def test_fast_collision_kernel_matches_generic_and_oracle(O, ne, fmax, en_r, en_
               "cls": np.zeros(n, dtype=int), "idx_diff": idx_d, "idx_sum": idx_s, "sign": sg, "dE": dE}
     s_ref, p_ref = state.copy(), ph.copy()
     O.collision_step(s_ref, p_ref, tables, 0.37, en_r=en_r, en_s=en_s, update_phonons=upd)
-    assert rel_err(outs[0][0], s_ref) < 1e-12 and rel_err(outs[0][1], p_ref) < 1e-11
+    # vs the host oracle the exp() last-bit caveat of solver.py:661,697 applies (see the golden-vector test above)
+    assert rel_err(outs[0][0], s_ref) < 2e-11 and rel_err(outs[0][1], p_ref) < 2e-11
 
 
 def test_merged_phonon_bins_fall_back_to_generic_kernel():
