@@ -23,6 +23,25 @@ __device__ __forceinline__ T uniform_const(const void* p) {
   return (T)(((unsigned long long)hi << 32) | lo);
 }
 
+// Returns the same wave-uniform pointer, but opaque to the optimiser: the scalar table loads made through it cannot be
+// hoisted above this point.  Without it all NE^2 kernel values are loaded up-front, overflow the ~100 SGPRs and are
+// parked in VGPRs (the register count then grows like 1.4 NE^2 and occupancy drops to one wave per SIMD).
+template <typename T>
+__device__ __forceinline__ T pin_here(T p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
+// Empty asm with the value as in/out operand: the value is "redefined" here, so every instruction that produced it
+// must come before and every consumer after.  Volatile asms keep their relative order (and their order against
+// stores and sched_barrier), which pure VALU instructions do not: without these pins the single huge basic block lets
+// instruction selection sink most accumulator FMAs of every diagonal to the end, with their K*P products kept live.
+template <int N>
+__device__ __forceinline__ void pin_array(double (&a)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(a[i]));
+}
+
 struct CollFastView {
   const double* kr0;      // [NE][NE] or NULL
   const double* ks0;      // [NE][NE] or NULL
@@ -46,16 +65,20 @@ __device__ __forceinline__ double affine_update_f(double y, double a, double b, 
   return fmax(ex * y + coeff * a, 0.0);
 }
 
-template <int NE>
+// USE_S / USE_R / UPD are compile-time: with run-time flags the compiler clones and threads the unrolled body into
+// flag-specific paths whose instructions it then interleaves across diagonals (several phonon values live at once).
+template <int NE, bool USE_S, bool USE_R, bool UPD>
 __global__ void __launch_bounds__(128) collision_diag_kernel(CollFastView t, const uint8_t* __restrict__ flags,
                                                              long ncell, const double* __restrict__ sin_,
                                                              double* __restrict__ sout, double* __restrict__ ph,
-                                                             double dE, double dt, int en_r, int en_s, int upd_ph) {
-  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= ncell) return;
+                                                             double dE, double dt) {
+  // p is kept as a 32-bit offset and every plane base is wave-uniform, so all plane accesses use the
+  // SGPR-base + 32-bit VGPR-offset addressing mode: no 64-bit address registers per plane (host checks ncell < 2^28)
+  const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (unsigned long)ncell) return;
   if (!(flags[p] & QP_FLAG_ACTIVE)) {
 #pragma unroll
-    for (int i = 0; i < NE; ++i) sout[(long)i * ncell + p] = sin_[(long)i * ncell + p];
+    for (int i = 0; i < NE; ++i) (sout + (long)i * ncell)[p] = (sin_ + (long)i * ncell)[p];
     return;
   }
   const cdtab_t rho = uniform_const<cdtab_t>(t.rho);
@@ -63,30 +86,35 @@ __global__ void __launch_bounds__(128) collision_diag_kernel(CollFastView t, con
   const cdtab_t kr = uniform_const<cdtab_t>(t.kr0);
   const citab_t dbin = uniform_const<citab_t>(t.diag_bin);
   const citab_t abin = uniform_const<citab_t>(t.anti_bin);
-  const bool use_s = en_s && t.ks0;
-  const bool use_r = en_r && t.kr0;
+  constexpr bool use_s = USE_S, use_r = USE_R, upd_ph = UPD;
 
   double n[NE], q[NE], ga[NE], la[NE];
 #pragma unroll
   for (int i = 0; i < NE; ++i) {
-    n[i] = sin_[(long)i * ncell + p];
+    n[i] = (sin_ + (long)i * ncell)[p];
     const double r = rho[i];
     q[i] = r * fmax(1.0 - n[i] / fmax(r, 1e-30), 0.0);
     ga[i] = 0.0;
     la[i] = 0.0;
   }
 
+  // One phonon occupation per (anti)diagonal; the next one is prefetched while the current one is processed.  The
+  // scheduling barriers keep the compiler from hoisting every load / exp chain to the top (which costs ~60 live
+  // doubles and halves the occupancy); with them the live set is n, q, ga, la plus one diagonal's temporaries.
   if (use_s) {
+    double Pnext = NE > 1 ? (ph + (long)dbin[1] * ncell)[p] : 0.0;
 #pragma unroll
     for (int k = 1; k < NE; ++k) {
-      double* pw = ph + (long)dbin[k] * ncell + p;
-      const double P = *pw;
+      double* pw = ph + (long)dbin[k] * ncell;
+      const cdtab_t ksk = pin_here(ks);
+      const double P = Pnext;
+      if (k + 1 < NE) Pnext = (ph + (long)dbin[k + 1] * ncell)[p];
       double em = 0.0, ab = 0.0;
 #pragma unroll
       for (int j = 0; j + k < NE; ++j) {
         const int i = j + k;                    // E_i > E_j: (i -> j) emits, (j -> i) absorbs
-        const double K = ks[i * NE + j];
-        const double t1 = K * P, t2 = K + t1;   // K n_BE-like factor P, and K (1 + P)
+        const double K = ksk[i * NE + j];
+        const double t1 = K * P, t2 = K + t1;   // K P and K (1 + P)
         ga[i] = fma(t1, n[j], ga[i]);
         la[i] = fma(t2, q[j], la[i]);
         ga[j] = fma(t2, n[i], ga[j]);
@@ -94,20 +122,26 @@ __global__ void __launch_bounds__(128) collision_diag_kernel(CollFastView t, con
         em = fma(n[i] * K, q[j], em);
         ab = fma(n[j] * K, q[i], ab);
       }
-      if (upd_ph) *pw = affine_update_f(P, dE * em, dE * (em - ab), dt);
+      if (upd_ph) pw[p] = affine_update_f(P, dE * em, dE * (em - ab), dt);
+      pin_array(ga);
+      pin_array(la);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   if (use_r) {
+    double Pnext = (ph + (long)abin[0] * ncell)[p];
 #pragma unroll
     for (int m = 0; m < 2 * NE - 1; ++m) {
-      double* pw = ph + (long)abin[m] * ncell + p;
-      const double P = *pw;
+      double* pw = ph + (long)abin[m] * ncell;
+      const cdtab_t krm = pin_here(kr);
+      const double P = Pnext;
+      if (m + 1 < 2 * NE - 1) Pnext = (ph + (long)abin[m + 1] * ncell)[p];
       double rec = 0.0, pb = 0.0;
 #pragma unroll
       for (int i = 0; i < NE; ++i) {
         const int j = m - i;
         if (j < 0 || j >= NE || j > i) continue;
-        const double K2 = 2.0 * kr[i * NE + j];
+        const double K2 = 2.0 * krm[i * NE + j];
         const double t1 = K2 * P, t2 = K2 + t1;
         if (i != j) {
           la[i] = fma(t2, n[j], la[i]);
@@ -123,29 +157,47 @@ __global__ void __launch_bounds__(128) collision_diag_kernel(CollFastView t, con
           pb = fma(0.5 * K2 * q[i], q[i], pb);
         }
       }
-      if (upd_ph) *pw = affine_update_f(P, dE * rec, dE * (rec - pb), dt);
+      if (upd_ph) pw[p] = affine_update_f(P, dE * rec, dE * (rec - pb), dt);
+      pin_array(ga);
+      pin_array(la);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 #pragma unroll
-  for (int i = 0; i < NE; ++i)
-    sout[(long)i * ncell + p] = relax_update_f(n[i], dE * q[i] * ga[i], dE * la[i], dt);
+  for (int i = 0; i < NE; ++i) {
+    (sout + (long)i * ncell)[p] = relax_update_f(n[i], dE * q[i] * ga[i], dE * la[i], dt);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int NE, bool S, bool R, bool U>
+static void launch_one(const CollFastView& v, const uint8_t* flags, long ncell, const double* sin_, double* sout,
+                       double* ph, double dE, double dt, hipStream_t stream) {
+  const unsigned blocks = (unsigned)((ncell + 127) / 128);
+  hipLaunchKernelGGL((collision_diag_kernel<NE, S, R, U>), dim3(blocks), dim3(128), 0, stream, v, flags, ncell, sin_,
+                     sout, ph, dE, dt);
 }
 
 template <int NE>
 static void launch_diag(const CollFastView& v, const uint8_t* flags, long ncell, const double* sin_, double* sout,
-                        double* ph, double dE, double dt, int en_r, int en_s, int upd, hipStream_t stream) {
-  const unsigned blocks = (unsigned)((ncell + 127) / 128);
-  hipLaunchKernelGGL(collision_diag_kernel<NE>, dim3(blocks), dim3(128), 0, stream, v, flags, ncell, sin_, sout, ph, dE,
-                     dt, en_r, en_s, upd);
+                        double* ph, double dE, double dt, bool s, bool r, bool u, hipStream_t stream) {
+#define QP_GO(S, R, U) launch_one<NE, S, R, U>(v, flags, ncell, sin_, sout, ph, dE, dt, stream)
+  if (s && r) { if (u) QP_GO(true, true, true); else QP_GO(true, true, false); }
+  else if (s) { if (u) QP_GO(true, false, true); else QP_GO(true, false, false); }
+  else if (r) { if (u) QP_GO(false, true, true); else QP_GO(false, true, false); }
+  else QP_GO(false, false, false);
+#undef QP_GO
 }
 
-// returns false when NE has no instantiation
+// returns false when NE has no instantiation or the cell count exceeds the 32-bit offset range
 bool collision_fast_dispatch(int ne, const double* kr0, const double* ks0, const double* rho, const int* diag_bin,
                              const int* anti_bin, const uint8_t* flags, long ncell, const double* sin_, double* sout,
                              double* ph, double dE, double dt, int en_r, int en_s, int upd, hipStream_t stream) {
+  if (ncell >= (1L << 28)) return false;
   CollFastView v{kr0, ks0, rho, diag_bin, anti_bin};
+  const bool s = en_s && ks0, r = en_r && kr0, u = upd && (s || r);
   switch (ne) {
-#define QP_CASE(N) case N: launch_diag<N>(v, flags, ncell, sin_, sout, ph, dE, dt, en_r, en_s, upd, stream); return true;
+#define QP_CASE(N) case N: launch_diag<N>(v, flags, ncell, sin_, sout, ph, dE, dt, s, r, u, stream); return true;
     QP_CASE(2) QP_CASE(3) QP_CASE(4) QP_CASE(5) QP_CASE(6) QP_CASE(7) QP_CASE(8) QP_CASE(9) QP_CASE(10) QP_CASE(11)
     QP_CASE(12) QP_CASE(13) QP_CASE(14) QP_CASE(15) QP_CASE(16)
 #undef QP_CASE
