@@ -52,6 +52,17 @@ class ADIWorkload:
 
     run_steps = run
 
+    def _pmc_traffic(self):
+        """HBM bytes per sweep launch from the committed PMC summary (profiles/, separate rocprofv3 --pmc passes of this
+        same command); only the configuration it was measured on gets a number."""
+        import json
+        from pathlib import Path
+        f = Path(__file__).resolve().parents[2] / "profiles" / "r01_adi4096_pmc.json"
+        if self.N != 4096 or self.nfield != 1 or self.op.rect is None or not f.exists():
+            return None
+        k = json.loads(f.read_text())["kernels"]
+        return 0.5 * (k["qp::rect_x_kernel"]["hbm_bytes_per_launch"] + k["qp::rect_y_kernel<1>"]["hbm_bytes_per_launch"])
+
     def roofline(self, nrep: int) -> dict:
         """Average duration of one sweep kernel launch (HIP events on the launch stream) vs algorithmic bytes."""
         torch = self.eng.torch
@@ -71,7 +82,7 @@ class ADIWorkload:
         bytes_per_launch = 16.0 * self.cell_updates_per_step         # 8 B read + 8 B write per cell per sweep
         achieved = bytes_per_launch / per_sweep_s / 1e9
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": self._pmc_traffic(),
                 "kernel": "rect_x_kernel / rect_y_kernel (one tile sweep)" if self.op.rect is not None else "thomas_lines_kernel",
                 "bytes_per_launch": bytes_per_launch, "avg_launch_us": per_sweep_s * 1e6,
                 "note": "launch time = (event time of k-step calls) / (2k+1 sweep launches); includes the reduced-system kernels"}
