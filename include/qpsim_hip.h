@@ -180,6 +180,35 @@ int qp_adi_rect_plan_destroy(qp_adi_rect_plan* plan);
 int qp_adi_rect_plan_decoupled(const qp_adi_rect_plan* plan, int32_t dir);
 int qp_adi_rect_steps(qp_adi_rect_plan* plan, double* u, int32_t nsteps, void* stream);
 
+/*
+ * Domain decomposition (one rank per GPU owns a ny x nx block at offset (j0, i0) of a gny x gnx grid; offsets and
+ * interior block extents are multiples of 64).  Only the decoupled-interface regime is supported across ranks
+ * (QP_ERR_UNSUPPORTED otherwise): the coupling between blocks is then the same 2x2 interface system as between
+ * 64-cell chunks inside a block, and each sweep needs from each neighbour one row of reduced right-hand sides
+ * (nfield x nlines doubles), the entry pass one row of the field.  The host sequences the phases and moves the rows
+ * (RCCL send/recv); a time step that starts from a materialised field is
+ *     [set_field_halo up/down] ENTRY [iface x] REDUCED_X SWEEP_X [iface y] REDUCED_Y SWEEP_Y_EXIT
+ * and consecutive steps replace SWEEP_Y_EXIT by SWEEP_Y_CARRY [iface x] REDUCED_X SWEEP_X ...
+ * qp_adi_rect_phase works on undecomposed plans too (it is what qp_adi_rect_steps calls).
+ */
+enum {
+  QP_ADI_ENTRY = 0,         /* u -> rhs of the x-solve (needs field halo rows), reduced rhs for x */
+  QP_ADI_REDUCED_X = 1,     /* banded reduced solve along x (no-op in the decoupled regime) */
+  QP_ADI_SWEEP_X = 2,       /* x-solve, rhs of the y-solve, reduced rhs for y */
+  QP_ADI_REDUCED_Y = 3,
+  QP_ADI_SWEEP_Y_CARRY = 4, /* y-solve, rhs of the next step's x-solve, reduced rhs for x */
+  QP_ADI_SWEEP_Y_EXIT = 5   /* y-solve, u' stored to u */
+};
+int qp_adi_rect_plan_create_block(int32_t ny, int32_t nx, int32_t nfield, double r, const double* dcoef_host,
+                                  const double* bc_diag, const double* bc_src, int32_t force_banded, int32_t gny,
+                                  int32_t gnx, int32_t j0, int32_t i0, qp_adi_rect_plan** out);
+int qp_adi_rect_phase(qp_adi_rect_plan* plan, int32_t phase, double* u, void* stream);
+/* dir 0: neighbours left (side 0) / right (side 1); dir 1: up / down.  op 0 packs the row the neighbour needs into
+ * buf[nfield][nlines], op 1 stores the neighbour's row into the halo slot on that side. */
+int qp_adi_rect_iface_halo(qp_adi_rect_plan* plan, int32_t dir, int32_t side, int32_t op, double* buf, void* stream);
+/* rows[nfield][nx]: the field row just above (side 0) / below (side 1) the block, consumed by QP_ADI_ENTRY. */
+int qp_adi_rect_set_field_halo(qp_adi_rect_plan* plan, int32_t side, const double* rows, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,8 +41,11 @@ constexpr double kFarCouplingDrop = 1e-22;
 enum { T_W = 0, T_AWF, T_AWB, T_CM, T_C0, T_CP, T_SRC, T_G, T_H, T_NSLOT };
 
 struct RectDims {
-  int ny, nx, nfield;
-  int py, px;                   // chunks per column / per row
+  int ny, nx, nfield;           // LOCAL block extent
+  int py, px;                   // local chunks per column / per row
+  int gny, gnx;                 // global grid extent (== ny, nx without decomposition)
+  int j0, i0;                   // global offset of the local block (multiples of 64)
+  int gpy, gpx;                 // global chunks per column / per row
 };
 
 struct RectView {
@@ -50,9 +53,15 @@ struct RectView {
   const double* alpha;          // [nfield]
   const double* tab;            // [2 dirs][nfield][4 variants][T_NSLOT][TS]
   const double* lu[2];          // per dir: [nfield][5][2P]  (l1, l2, uinv, u1, u2)
-  double* iface[2];             // per dir: [nfield][2P][nlines]   reduced right-hand sides
+  // reduced right-hand sides, per dir [nfield][2P+2][nlines]: row 0 = y[last] of the chunk before the local block,
+  // rows 1..2P = (y_0[0], y_0[last], y_1[0], ...), row 2P+1 = y[0] of the chunk after the block.  The two halo rows
+  // are filled by the neighbouring rank (domain decomposition) and unused otherwise.
+  double* iface[2];
   double* z[2];                 // per dir: [nfield][2P][nlines]   reduced solutions (F_0, E_0, F_1, E_1, ...)
-  const double* icoef[2];       // per dir: [nfield][P][3]  (s, t, 1/(1 - s t)) of the interface between chunk p and p+1
+  // per dir [nfield][P+1][3]: (s, t, 1/(1 - s t)) of the interface between local chunks q-1 and q (q = 0 and q = P are
+  // the interfaces to the neighbouring blocks)
+  const double* icoef[2];
+  const double* uhalo[2];       // [nfield][nx]: field row just above / below the local block (entry pass, decomposed)
   int decoupled[2];             // per dir: far couplings underflow -> every interface is an independent 2 x 2 system
   double other_src[2][2];       // [dir][lo/hi]: a-less source of the faces normal to `dir` (x: sx_lo, sx_hi)
 };
@@ -212,20 +221,22 @@ template <int DIR>
 __device__ __forceinline__ void chunk_ghosts(const RectView& v, int b, int p, long line, bool on, double& gl,
                                              double& gr) {
   const int P = DIR == 0 ? v.d.px : v.d.py;
+  const int pg = p + (DIR == 0 ? v.d.i0 : v.d.j0) / TS;          // global chunk index
+  const int PG = DIR == 0 ? v.d.gpx : v.d.gpy;
   const long nlines = DIR == 0 ? v.d.ny : v.d.nx;
   gl = 0.0;
   gr = 0.0;
   if (!on) return;
   if (v.decoupled[DIR]) {
-    const double* ir = v.iface[DIR] + (long)b * 2 * P * nlines + line;
-    const ctab_t ic = as_const(v.icoef[DIR] + (long)b * P * 3);
-    if (p > 0) {
-      const double yl = ir[(long)(2 * p - 1) * nlines], yf = ir[(long)(2 * p) * nlines];
-      gl = fma(ic[(p - 1) * 3], yf, yl) * ic[(p - 1) * 3 + 2];
+    const double* ir = v.iface[DIR] + (long)b * (2 * P + 2) * nlines + line;
+    const ctab_t ic = as_const(v.icoef[DIR] + (long)b * (P + 1) * 3);
+    if (pg > 0) {
+      const double yl = ir[(long)(2 * p) * nlines], yf = ir[(long)(2 * p + 1) * nlines];
+      gl = fma(ic[p * 3], yf, yl) * ic[p * 3 + 2];
     }
-    if (p < P - 1) {
-      const double yl = ir[(long)(2 * p + 1) * nlines], yf = ir[(long)(2 * p + 2) * nlines];
-      gr = fma(ic[p * 3 + 1], yl, yf) * ic[p * 3 + 2];
+    if (pg < PG - 1) {
+      const double yl = ir[(long)(2 * p + 2) * nlines], yf = ir[(long)(2 * p + 3) * nlines];
+      gr = fma(ic[(p + 1) * 3 + 1], yl, yf) * ic[(p + 1) * 3 + 2];
     }
   } else {
     const double* z = v.z[DIR] + (long)b * 2 * P * nlines + line;
@@ -252,23 +263,23 @@ __global__ void __launch_bounds__(64) rect_x_kernel(RectView v, double* __restri
   const bool row_on = lane < t.nr;
   double gl, gr;
   chunk_ghosts<0>(v, t.b, t.tx, row, row_on, gl, gr);
-  const ctab_t tx_tab = table_ptr(v, 0, t.b, chunk_variant(t.tx, v.d.px));
+  const ctab_t tx_tab = table_ptr(v, 0, t.b, chunk_variant(t.tx + v.d.i0 / TS, v.d.gpx));
   e[0] = fma(a, gl, e[0]);
   e[TS - 1] = fma(a, gr, e[TS - 1]);   // gr != 0 only for full-length chunks
   thomas64(e, tx_tab);
   double srow = 0.0;                   // sources of the y-faces (up/down) belong to rows 0 and ny-1
-  if (row == 0) srow += a * v.other_src[1][0];
-  if (row == v.d.ny - 1) srow += a * v.other_src[1][1];
+  if (row + v.d.j0 == 0) srow += a * v.other_src[1][0];
+  if (row + v.d.j0 == v.d.gny - 1) srow += a * v.other_src[1][1];
   explicit64(e, gl, gr, tx_tab, row_on ? srow : 0.0);
   transpose64(e, lds, lane);
   // lane = column again
   store_cols(plane, t, v.d.nx, lane, e);
   double yf, yl;
-  dots64(e, table_ptr(v, 1, t.b, chunk_variant(t.ty, v.d.py)), yf, yl);
+  dots64(e, table_ptr(v, 1, t.b, chunk_variant(t.ty + v.d.j0 / TS, v.d.gpy)), yf, yl);
   if (lane < t.nc) {
-    double* ir = v.iface[1] + (long)t.b * 2 * v.d.py * v.d.nx;
-    ir[(long)(2 * t.ty) * v.d.nx + t.i0 + lane] = yf;
-    ir[(long)(2 * t.ty + 1) * v.d.nx + t.i0 + lane] = yl;
+    double* ir = v.iface[1] + (long)t.b * (2 * v.d.py + 2) * v.d.nx;
+    ir[(long)(2 * t.ty + 1) * v.d.nx + t.i0 + lane] = yf;
+    ir[(long)(2 * t.ty + 2) * v.d.nx + t.i0 + lane] = yl;
   }
 }
 
@@ -288,13 +299,17 @@ __global__ void __launch_bounds__(64) rect_y_kernel(RectView v, const double* sr
   const double a = as_const(v.alpha)[t.b];
   const int col = t.i0 + lane;
   const bool col_on = lane < t.nc;
-  const ctab_t ty_tab = table_ptr(v, 1, t.b, chunk_variant(t.ty, v.d.py));
+  const ctab_t ty_tab = table_ptr(v, 1, t.b, chunk_variant(t.ty + v.d.j0 / TS, v.d.gpy));
   double e[TS];
   load_cols(splane, t, v.d.nx, lane, e);
   double gu = 0.0, gd = 0.0;           // values of the field just above / below the tile
   if (MODE == 0) {
-    if (col_on && t.ty > 0) gu = splane[(long)(t.j0 - 1) * v.d.nx + col];
-    if (col_on && t.ty < v.d.py - 1) gd = splane[(long)(t.j0 + TS) * v.d.nx + col];
+    if (col_on) {
+      if (t.ty > 0) gu = splane[(long)(t.j0 - 1) * v.d.nx + col];
+      else if (v.d.j0 > 0) gu = v.uhalo[0][(long)t.b * v.d.nx + col];                 // row owned by the rank above
+      if (t.ty < v.d.py - 1) gd = splane[(long)(t.j0 + TS) * v.d.nx + col];
+      else if (v.d.j0 + v.d.ny < v.d.gny) gd = v.uhalo[1][(long)t.b * v.d.nx + col];  // row owned by the rank below
+    }
   } else {
     chunk_ghosts<1>(v, t.b, t.ty, col, col_on, gu, gd);
     e[0] = fma(a, gu, e[0]);
@@ -306,17 +321,17 @@ __global__ void __launch_bounds__(64) rect_y_kernel(RectView v, const double* sr
     return;
   }
   double scol = 0.0;                   // sources of the x-faces (left/right) belong to columns 0 and nx-1
-  if (col == 0) scol += a * v.other_src[0][0];
-  if (col == v.d.nx - 1) scol += a * v.other_src[0][1];
+  if (col + v.d.i0 == 0) scol += a * v.other_src[0][0];
+  if (col + v.d.i0 == v.d.gnx - 1) scol += a * v.other_src[0][1];
   explicit64(e, gu, gd, ty_tab, col_on ? scol : 0.0);
   store_cols(dplane, t, v.d.nx, lane, e);
   transpose64(e, lds, lane);
   double yf, yl;
-  dots64(e, table_ptr(v, 0, t.b, chunk_variant(t.tx, v.d.px)), yf, yl);
+  dots64(e, table_ptr(v, 0, t.b, chunk_variant(t.tx + v.d.i0 / TS, v.d.gpx)), yf, yl);
   if (lane < t.nr) {
-    double* ir = v.iface[0] + (long)t.b * 2 * v.d.px * v.d.ny;
-    ir[(long)(2 * t.tx) * v.d.ny + t.j0 + lane] = yf;
-    ir[(long)(2 * t.tx + 1) * v.d.ny + t.j0 + lane] = yl;
+    double* ir = v.iface[0] + (long)t.b * (2 * v.d.px + 2) * v.d.ny;
+    ir[(long)(2 * t.tx + 1) * v.d.ny + t.j0 + lane] = yf;
+    ir[(long)(2 * t.tx + 2) * v.d.ny + t.j0 + lane] = yl;
   }
 }
 
@@ -331,7 +346,7 @@ __global__ void __launch_bounds__(64) rect_reduced_kernel(RectView v, int dir) {
   const int b = (int)(gid / nlines);
   const int line = (int)(gid - (long)b * nlines);
   const double* lu = v.lu[dir] + (long)b * 5 * m;
-  const double* rhs = v.iface[dir] + (long)b * m * nlines + line;
+  const double* rhs = v.iface[dir] + ((long)b * (m + 2) + 1) * nlines + line;
   double* z = v.z[dir] + (long)b * m * nlines + line;
   double y1 = 0.0, y2 = 0.0;  // y_{i-1}, y_{i-2}
   for (int i = 0; i < m; ++i) {
@@ -421,31 +436,47 @@ static void build_chunk_table(const DirSpec& s, double a, int p, double* tab, do
   ends[3] = h[len - 1];
 }
 
-// banded LU (2 sub-, 2 super-diagonals, no pivoting: the matrix is strictly diagonally dominant)
-// also fills icoef[P][3] (interface p | p+1) and returns the largest far-coupling weight of the reduced matrix
-static double reduced_lu(const DirSpec& s, double a, double* lu /*[5][2P]*/, double* icoef /*[P][3]*/) {
-  const int m = 2 * s.P;
-  std::vector<double> A((size_t)m * m, 0.0);
+// Reduced-system data of one (field, direction).  `s` describes the GLOBAL line; the local block holds chunks
+// [p0, p0 + Ploc).  Fills icoef[Ploc+1][3] (interface q sits between local chunks q-1 and q; q = 0 / Ploc touch the
+// neighbouring blocks) and, when `lu` is non-NULL (no decomposition: p0 == 0, Ploc == s.P), the banded LU factors
+// [5][2P] (2 sub-, 2 super-diagonals, no pivoting: the matrix is strictly diagonally dominant).  Returns the largest
+// far-coupling weight of the global reduced matrix.
+static double reduced_tables(const DirSpec& s, double a, int p0, int Ploc, double* lu, double* icoef) {
   std::vector<double> tab(TS * T_NSLOT);
-  std::vector<double> near_g(s.P), near_h(s.P);
+  std::vector<double> near_g(s.P), near_h(s.P), far_g(s.P), far_h(s.P);
   double far = 0.0;
   for (int p = 0; p < s.P; ++p) {
     double ends[4];
     build_chunk_table(s, a, p, tab.data(), ends);
     near_g[p] = a * ends[0];   // weight of E_{p-1} in the F_p equation
+    far_g[p] = a * ends[1];    // weight of E_{p-1} in the E_p equation
+    far_h[p] = a * ends[2];    // weight of F_{p+1} in the F_p equation
     near_h[p] = a * ends[3];   // weight of F_{p+1} in the E_p equation
-    if (p > 0) far = std::max(far, std::fabs(a * ends[1]));
-    if (p < s.P - 1) far = std::max(far, std::fabs(a * ends[2]));
+    if (p > 0) far = std::max(far, std::fabs(far_g[p]));
+    if (p < s.P - 1) far = std::max(far, std::fabs(far_h[p]));
+  }
+  for (int q = 0; q <= Ploc; ++q) {
+    const int pl = p0 + q - 1, pr = p0 + q;   // global chunks left / right of the interface
+    const double sc = (pl >= 0 && pr < s.P) ? near_h[pl] : 0.0;
+    const double tc = (pl >= 0 && pr < s.P) ? near_g[pr] : 0.0;
+    icoef[q * 3] = sc;
+    icoef[q * 3 + 1] = tc;
+    icoef[q * 3 + 2] = 1.0 / (1.0 - sc * tc);
+  }
+  if (!lu) return far;
+  const int m = 2 * s.P;
+  std::vector<double> A((size_t)m * m, 0.0);
+  for (int p = 0; p < s.P; ++p) {
     const int f = 2 * p, e = 2 * p + 1;
     A[(size_t)f * m + f] = 1.0;
     A[(size_t)e * m + e] = 1.0;
     if (p > 0) {
-      A[(size_t)f * m + (2 * p - 1)] += -a * ends[0];
-      A[(size_t)e * m + (2 * p - 1)] += -a * ends[1];
+      A[(size_t)f * m + (2 * p - 1)] += -near_g[p];
+      A[(size_t)e * m + (2 * p - 1)] += -far_g[p];
     }
     if (p < s.P - 1) {
-      A[(size_t)f * m + (2 * p + 2)] += -a * ends[2];
-      A[(size_t)e * m + (2 * p + 2)] += -a * ends[3];
+      A[(size_t)f * m + (2 * p + 2)] += -far_h[p];
+      A[(size_t)e * m + (2 * p + 2)] += -near_h[p];
     }
   }
   for (int k = 0; k < m; ++k) {
@@ -462,12 +493,6 @@ static double reduced_lu(const DirSpec& s, double a, double* lu /*[5][2P]*/, dou
     lu[3 * m + i] = i + 1 < m ? A[(size_t)i * m + i + 1] : 0.0;
     lu[4 * m + i] = i + 2 < m ? A[(size_t)i * m + i + 2] : 0.0;
   }
-  for (int p = 0; p < s.P; ++p) {
-    const double sc = near_h[p], tc = p + 1 < s.P ? near_g[p + 1] : 0.0;
-    icoef[p * 3] = sc;
-    icoef[p * 3 + 1] = tc;
-    icoef[p * 3 + 2] = 1.0 / (1.0 - sc * tc);
-  }
   return far;
 }
 
@@ -481,8 +506,10 @@ struct qp_adi_rect_plan {
   double* d_icoef[2] = {nullptr, nullptr};
   double* d_iface[2] = {nullptr, nullptr};
   double* d_z[2] = {nullptr, nullptr};
+  double* d_uhalo[2] = {nullptr, nullptr};
   double* d_work = nullptr;  // [nfield][ncell] carried right-hand side
   long ncell = 0;
+  bool decomposed = false;
 };
 
 extern "C" {
@@ -496,28 +523,39 @@ int qp_adi_rect_plan_destroy(qp_adi_rect_plan* plan) {
     (void)hipFree(plan->d_icoef[d]);
     (void)hipFree(plan->d_iface[d]);
     (void)hipFree(plan->d_z[d]);
+    (void)hipFree(plan->d_uhalo[d]);
   }
   (void)hipFree(plan->d_work);
   delete plan;
   return QP_OK;
 }
 
-int qp_adi_rect_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, const double* dcoef_host,
-                            const double* bc_diag, const double* bc_src, int32_t force_banded,
-                            qp_adi_rect_plan** out) {
+int qp_adi_rect_plan_create_block(int32_t ny, int32_t nx, int32_t nfield, double r, const double* dcoef_host,
+                                  const double* bc_diag, const double* bc_src, int32_t force_banded, int32_t gny,
+                                  int32_t gnx, int32_t j0, int32_t i0, qp_adi_rect_plan** out) {
   QP_REQUIRE(out != nullptr, "out is NULL");
   *out = nullptr;
   QP_REQUIRE(ny > 0 && nx > 0 && nfield > 0, "ny, nx, nfield must be positive");
   QP_REQUIRE(r > 0.0 && dcoef_host && bc_diag && bc_src, "r must be positive; dcoef/bc arrays non-NULL");
-  for (int b = 0; b < nfield; ++b) QP_REQUIRE(dcoef_host[b] >= 0.0, "diffusion coefficients must be >= 0");
+  QP_REQUIRE(j0 >= 0 && i0 >= 0 && j0 + ny <= gny && i0 + nx <= gnx, "block must lie inside the global grid");
   using namespace qp;
+  QP_REQUIRE(j0 % TS == 0 && i0 % TS == 0, "block offsets must be multiples of 64");
+  QP_REQUIRE((j0 + ny == gny || ny % TS == 0) && (i0 + nx == gnx || nx % TS == 0),
+             "interior block extents must be multiples of 64");
+  for (int b = 0; b < nfield; ++b) QP_REQUIRE(dcoef_host[b] >= 0.0, "diffusion coefficients must be >= 0");
+  const bool decomposed = !(gny == ny && gnx == nx);
+  QP_REQUIRE(!(decomposed && force_banded), "the banded reduced solve is not available on decomposed grids");
   auto* plan = new qp_adi_rect_plan();
+  plan->decomposed = decomposed;
   RectView& v = plan->view;
-  v.d = RectDims{ny, nx, nfield, (ny + TS - 1) / TS, (nx + TS - 1) / TS};
+  v.d = RectDims{ny, nx, nfield, (ny + TS - 1) / TS, (nx + TS - 1) / TS, gny, gnx, j0, i0,
+                 (gny + TS - 1) / TS, (gnx + TS - 1) / TS};
   plan->ncell = (long)ny * nx;
-  // bc_* order: left, right, up, down  (x-faces then y-faces)
-  DirSpec spec[2] = {{nx, v.d.px, bc_diag[0], bc_diag[1], bc_src[0], bc_src[1]},
-                     {ny, v.d.py, bc_diag[2], bc_diag[3], bc_src[2], bc_src[3]}};
+  // bc_* order: left, right, up, down  (x-faces then y-faces); specs describe the GLOBAL lines
+  DirSpec spec[2] = {{gnx, v.d.gpx, bc_diag[0], bc_diag[1], bc_src[0], bc_src[1]},
+                     {gny, v.d.gpy, bc_diag[2], bc_diag[3], bc_src[2], bc_src[3]}};
+  const int ploc[2] = {v.d.px, v.d.py};
+  const int p0[2] = {i0 / TS, j0 / TS};
   v.other_src[0][0] = bc_src[0];
   v.other_src[0][1] = bc_src[1];
   v.other_src[1][0] = bc_src[2];
@@ -528,15 +566,15 @@ int qp_adi_rect_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, co
   std::vector<double> lu[2], icoef[2];
   double far[2] = {0.0, 0.0};
   for (int d = 0; d < 2; ++d) {
-    lu[d].assign((size_t)nfield * 5 * 2 * spec[d].P, 0.0);
-    icoef[d].assign((size_t)nfield * spec[d].P * 3, 0.0);
+    lu[d].assign(decomposed ? 1 : (size_t)nfield * 5 * 2 * spec[d].P, 0.0);
+    icoef[d].assign((size_t)nfield * (ploc[d] + 1) * 3, 0.0);
   }
   for (int b = 0; b < nfield; ++b) {
     const double a = r * dcoef_host[b];
     alpha[b] = a;
     for (int d = 0; d < 2; ++d) {
       const int P = spec[d].P;
-      // representative chunk per variant: interior -> 1, first -> 0, last -> P-1, single -> 0
+      // representative global chunk per variant: interior -> 1, first -> 0, last -> P-1, single -> 0
       for (int var = 0; var < 4; ++var) {
         int p;
         if (var == 0) { if (P < 3) continue; p = 1; }
@@ -546,19 +584,33 @@ int qp_adi_rect_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, co
         double ends[4];
         build_chunk_table(spec[d], a, p, &tab[((((size_t)d * nfield + b) * 4 + var) * T_NSLOT) * TS], ends);
       }
-      far[d] = std::max(far[d], reduced_lu(spec[d], a, &lu[d][(size_t)b * 5 * 2 * P], &icoef[d][(size_t)b * P * 3]));
+      far[d] = std::max(far[d], reduced_tables(spec[d], a, p0[d], ploc[d],
+                                               decomposed ? nullptr : &lu[d][(size_t)b * 5 * 2 * P],
+                                               &icoef[d][(size_t)b * (ploc[d] + 1) * 3]));
     }
+  }
+  for (int d = 0; d < 2; ++d) v.decoupled[d] = (force_banded == 0 && far[d] < kFarCouplingDrop) ? 1 : 0;
+  if (decomposed && !(v.decoupled[0] && v.decoupled[1])) {
+    delete plan;
+    set_error("qp_adi_rect_plan_create_block: r*D too large for a decomposed grid (couplings between 64-cell chunks "
+              "%.3g / %.3g exceed %.0e; the global banded reduced solve is not implemented across ranks)",
+              far[0], far[1], kFarCouplingDrop);
+    return QP_ERR_UNSUPPORTED;
   }
   auto upload = [](const std::vector<double>& h, double** dptr) -> bool {
     if (hipMalloc((void**)dptr, h.size() * sizeof(double)) != hipSuccess) return false;
     return hipMemcpy(*dptr, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
   };
+  auto zalloc = [](double** dptr, size_t count) -> bool {
+    if (hipMalloc((void**)dptr, count * sizeof(double)) != hipSuccess) return false;
+    return hipMemset(*dptr, 0, count * sizeof(double)) == hipSuccess;
+  };
   bool ok = upload(alpha, &plan->d_alpha) && upload(tab, &plan->d_tab);
   for (int d = 0; d < 2 && ok; ++d) {
     const size_t nlines = d == 0 ? ny : nx;
-    const size_t cnt = (size_t)nfield * 2 * spec[d].P * nlines;
-    ok = upload(lu[d], &plan->d_lu[d]) && upload(icoef[d], &plan->d_icoef[d]) && hipMalloc((void**)&plan->d_iface[d], cnt * sizeof(double)) == hipSuccess &&
-         hipMalloc((void**)&plan->d_z[d], cnt * sizeof(double)) == hipSuccess;
+    ok = upload(lu[d], &plan->d_lu[d]) && upload(icoef[d], &plan->d_icoef[d]) &&
+         zalloc(&plan->d_iface[d], (size_t)nfield * (2 * ploc[d] + 2) * nlines) &&
+         zalloc(&plan->d_z[d], (size_t)nfield * 2 * ploc[d] * nlines) && zalloc(&plan->d_uhalo[d], (size_t)nfield * nx);
   }
   ok = ok && hipMalloc((void**)&plan->d_work, (size_t)nfield * plan->ncell * sizeof(double)) == hipSuccess;
   if (!ok) {
@@ -572,12 +624,18 @@ int qp_adi_rect_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, co
   for (int d = 0; d < 2; ++d) {
     v.lu[d] = plan->d_lu[d];
     v.icoef[d] = plan->d_icoef[d];
-    v.decoupled[d] = (force_banded == 0 && far[d] < kFarCouplingDrop) ? 1 : 0;
     v.iface[d] = plan->d_iface[d];
     v.z[d] = plan->d_z[d];
+    v.uhalo[d] = plan->d_uhalo[d];
   }
   *out = plan;
   return QP_OK;
+}
+
+int qp_adi_rect_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, const double* dcoef_host,
+                            const double* bc_diag, const double* bc_src, int32_t force_banded,
+                            qp_adi_rect_plan** out) {
+  return qp_adi_rect_plan_create_block(ny, nx, nfield, r, dcoef_host, bc_diag, bc_src, force_banded, ny, nx, 0, 0, out);
 }
 
 int qp_adi_rect_plan_decoupled(const qp_adi_rect_plan* plan, int32_t dir) {
@@ -585,27 +643,96 @@ int qp_adi_rect_plan_decoupled(const qp_adi_rect_plan* plan, int32_t dir) {
   return plan->view.decoupled[dir];
 }
 
-int qp_adi_rect_steps(qp_adi_rect_plan* plan, double* u, int32_t nsteps, void* stream_) {
-  QP_REQUIRE(plan && u, "plan and u must be non-NULL");
-  QP_REQUIRE(nsteps >= 1, "nsteps must be >= 1");
+int qp_adi_rect_phase(qp_adi_rect_plan* plan, int32_t phase, double* u, void* stream_) {
+  QP_REQUIRE(plan != nullptr, "plan is NULL");
   using namespace qp;
   hipStream_t stream = (hipStream_t)stream_;
   const RectView& v = plan->view;
   const unsigned tiles = (unsigned)((long)v.d.nfield * v.d.py * v.d.px);
-  const unsigned redx = (unsigned)(((long)v.d.ny * v.d.nfield + 63) / 64);
-  const unsigned redy = (unsigned)(((long)v.d.nx * v.d.nfield + 63) / 64);
   double* w = plan->d_work;
-  hipLaunchKernelGGL(rect_y_kernel<0>, dim3(tiles), dim3(64), 0, stream, v, (const double*)u, w);
-  for (int s = 0; s < nsteps; ++s) {
-    if (!v.decoupled[0]) hipLaunchKernelGGL(rect_reduced_kernel, dim3(redx), dim3(64), 0, stream, v, 0);
-    hipLaunchKernelGGL(rect_x_kernel, dim3(tiles), dim3(64), 0, stream, v, w);
-    if (!v.decoupled[1]) hipLaunchKernelGGL(rect_reduced_kernel, dim3(redy), dim3(64), 0, stream, v, 1);
-    if (s + 1 < nsteps)
+  switch (phase) {
+    case QP_ADI_ENTRY:
+      QP_REQUIRE(u != nullptr, "u is NULL");
+      hipLaunchKernelGGL(rect_y_kernel<0>, dim3(tiles), dim3(64), 0, stream, v, (const double*)u, w);
+      break;
+    case QP_ADI_REDUCED_X:
+      if (!v.decoupled[0])
+        hipLaunchKernelGGL(rect_reduced_kernel, dim3((unsigned)(((long)v.d.ny * v.d.nfield + 63) / 64)), dim3(64), 0,
+                           stream, v, 0);
+      break;
+    case QP_ADI_SWEEP_X:
+      hipLaunchKernelGGL(rect_x_kernel, dim3(tiles), dim3(64), 0, stream, v, w);
+      break;
+    case QP_ADI_REDUCED_Y:
+      if (!v.decoupled[1])
+        hipLaunchKernelGGL(rect_reduced_kernel, dim3((unsigned)(((long)v.d.nx * v.d.nfield + 63) / 64)), dim3(64), 0,
+                           stream, v, 1);
+      break;
+    case QP_ADI_SWEEP_Y_CARRY:
       hipLaunchKernelGGL(rect_y_kernel<1>, dim3(tiles), dim3(64), 0, stream, v, (const double*)w, w);
-    else
+      break;
+    case QP_ADI_SWEEP_Y_EXIT:
+      QP_REQUIRE(u != nullptr, "u is NULL");
       hipLaunchKernelGGL(rect_y_kernel<2>, dim3(tiles), dim3(64), 0, stream, v, (const double*)w, u);
+      break;
+    default:
+      set_error("qp_adi_rect_phase: unknown phase %d", phase);
+      return QP_ERR_INVALID_ARGUMENT;
   }
-  return check_launch("qp_adi_rect_steps");
+  return check_launch("qp_adi_rect_phase");
+}
+
+int qp_adi_rect_steps(qp_adi_rect_plan* plan, double* u, int32_t nsteps, void* stream) {
+  QP_REQUIRE(plan && u, "plan and u must be non-NULL");
+  QP_REQUIRE(nsteps >= 1, "nsteps must be >= 1");
+  QP_REQUIRE(!plan->decomposed, "a decomposed plan needs halo exchanges between phases: drive it with qp_adi_rect_phase");
+  int rc = qp_adi_rect_phase(plan, QP_ADI_ENTRY, u, stream);
+  for (int s = 0; s < nsteps && rc == QP_OK; ++s) {
+    rc = qp_adi_rect_phase(plan, QP_ADI_REDUCED_X, u, stream);
+    if (rc == QP_OK) rc = qp_adi_rect_phase(plan, QP_ADI_SWEEP_X, u, stream);
+    if (rc == QP_OK) rc = qp_adi_rect_phase(plan, QP_ADI_REDUCED_Y, u, stream);
+    if (rc == QP_OK) rc = qp_adi_rect_phase(plan, s + 1 < nsteps ? QP_ADI_SWEEP_Y_CARRY : QP_ADI_SWEEP_Y_EXIT, u, stream);
+  }
+  return rc;
+}
+
+// Boundary rows of the reduced right-hand sides <-> contiguous [nfield][nlines] buffers (domain decomposition).
+// dir 0: lines are rows, neighbours are left (side 0) / right (side 1); dir 1: columns, up (0) / down (1).
+// op 0 (pack): the row the neighbour on `side` needs (side 0: y[0] of my first chunk; side 1: y[last] of my last chunk).
+// op 1 (unpack): store the neighbour's row into my halo slot on `side`.
+int qp_adi_rect_iface_halo(qp_adi_rect_plan* plan, int32_t dir, int32_t side, int32_t op, double* buf, void* stream) {
+  QP_REQUIRE(plan && buf, "plan and buf must be non-NULL");
+  QP_REQUIRE((dir == 0 || dir == 1) && (side == 0 || side == 1) && (op == 0 || op == 1), "dir, side, op must be 0 or 1");
+  const qp::RectView& v = plan->view;
+  const size_t nlines = dir == 0 ? v.d.ny : v.d.nx;
+  const int P = dir == 0 ? v.d.px : v.d.py;
+  const size_t rows = 2 * (size_t)P + 2;
+  size_t row;
+  if (op == 0) row = side == 0 ? 1 : 2 * (size_t)P;
+  else row = side == 0 ? 0 : 2 * (size_t)P + 1;
+  double* strided = plan->d_iface[dir] + row * nlines;
+  const size_t w = nlines * sizeof(double), pitch = rows * nlines * sizeof(double);
+  hipError_t e = op == 0
+                     ? hipMemcpy2DAsync(buf, w, strided, pitch, w, v.d.nfield, hipMemcpyDeviceToDevice, (hipStream_t)stream)
+                     : hipMemcpy2DAsync(strided, pitch, buf, w, w, v.d.nfield, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+  if (e != hipSuccess) {
+    qp::set_error("qp_adi_rect_iface_halo: %s", hipGetErrorString(e));
+    return QP_ERR_LAUNCH;
+  }
+  return QP_OK;
+}
+
+// Field rows just above (side 0) / below (side 1) the local block, [nfield][nx], for the entry pass of a decomposed plan.
+int qp_adi_rect_set_field_halo(qp_adi_rect_plan* plan, int32_t side, const double* rows, void* stream) {
+  QP_REQUIRE(plan && rows && (side == 0 || side == 1), "bad arguments");
+  const qp::RectView& v = plan->view;
+  hipError_t e = hipMemcpyAsync(plan->d_uhalo[side], rows, (size_t)v.d.nfield * v.d.nx * sizeof(double),
+                                hipMemcpyDeviceToDevice, (hipStream_t)stream);
+  if (e != hipSuccess) {
+    qp::set_error("qp_adi_rect_set_field_halo: %s", hipGetErrorString(e));
+    return QP_ERR_LAUNCH;
+  }
+  return QP_OK;
 }
 
 }  // extern "C"

@@ -196,14 +196,17 @@ def structured_bin_maps(idx_diff, idx_sum, sign):
 class RectPlan:
     """Owner of a ``qp_adi_rect_plan`` (device tables + work planes of the fast full-rectangle ADI path)."""
 
-    def __init__(self, lib, ny, nx, nfield, r, dcoef, bc_diag, bc_src, force_banded: bool = False):
+    def __init__(self, lib, ny, nx, nfield, r, dcoef, bc_diag, bc_src, force_banded: bool = False, block=None):
+        """``block = (gny, gnx, j0, i0)`` makes this the plan of one block of a decomposed gny x gnx grid."""
         self._lib = lib
         self._h = C.POINTER(_hip.RectPlan)()
         dc = (C.c_double * nfield)(*[float(v) for v in dcoef])
         bd = (C.c_double * 4)(*bc_diag)
         bs = (C.c_double * 4)(*bc_src)
-        _hip.check(lib.qp_adi_rect_plan_create(ny, nx, nfield, float(r), dc, bd, bs, int(bool(force_banded)),
-                                               C.byref(self._h)), "qp_adi_rect_plan_create")
+        gny, gnx, j0, i0 = (ny, nx, 0, 0) if block is None else block
+        _hip.check(lib.qp_adi_rect_plan_create_block(ny, nx, nfield, float(r), dc, bd, bs, int(bool(force_banded)),
+                                                     int(gny), int(gnx), int(j0), int(i0), C.byref(self._h)),
+                   "qp_adi_rect_plan_create_block")
         self.decoupled = (bool(lib.qp_adi_rect_plan_decoupled(self._h, 0)), bool(lib.qp_adi_rect_plan_decoupled(self._h, 1)))
 
     @property

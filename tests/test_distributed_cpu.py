@@ -1,0 +1,123 @@
+"""N > 1 paths on CPU: partitioning, the decomposed step sequence with in-process virtual ranks, and the same sequence
+across two real processes over gloo (world_size 2)."""
+from __future__ import annotations
+
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dd_reference import NumpyBlockBackend
+from oracle import qp_oracle as O
+from qpsim_amd.distributed import (BlockTopology, TorchDistTransport, block_adi_steps, choose_process_grid,
+                                   lockstep_adi_steps, shard_members, split_extent)
+from qpsim_amd.geometry import extract_edge_segments
+from qpsim_amd.models import BoundaryCondition
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_member_sharding_and_extent_splitting():
+    assert shard_members(10, 4, 1) == [1, 5, 9]
+    assert sorted(sum((shard_members(512, 8, r) for r in range(8)), [])) == list(range(512))
+    assert split_extent(8192, 4) == [(0, 2048), (2048, 2048), (4096, 2048), (6144, 2048)]
+    assert split_extent(200, 2) == [(0, 128), (128, 72)]
+    assert split_extent(64, 1) == [(0, 64)]
+    with pytest.raises(ValueError):
+        split_extent(100, 3)
+    assert choose_process_grid(8, 8192, 8192) == (2, 4)
+    assert choose_process_grid(2, 8192, 8192) == (1, 2) and choose_process_grid(4, 1, 1) == (2, 2)
+    t = BlockTopology(8192, 8192, 2, 4, 5)
+    assert t.coords == (1, 1) and t.block == (4096, 2048, 4096, 2048)
+    assert t.neighbour(0, 0) == 4 and t.neighbour(0, 1) == 6 and t.neighbour(1, 0) == 1 and t.neighbour(1, 1) is None
+
+
+def _problem(gny, gnx):
+    side_bc = {"left": BoundaryCondition("dirichlet", 0.7), "right": BoundaryCondition("robin", 0.4, 0.2),
+               "up": BoundaryCondition("neumann", -0.3), "down": BoundaryCondition("absorbing")}
+    mask = np.ones((gny, gnx), dtype=bool)
+    edges = extract_edge_segments(mask)
+    bcs = {e.edge_id: side_bc[e.normal] for e in edges}
+    dx, dt, D = 0.9, 0.11, [6.0, 0.35]
+    from qpsim_amd.engine import compile_geometry, rect_side_terms
+    bc_diag, bc_src = rect_side_terms(compile_geometry(mask, edges, bcs, dx))
+    u0 = np.random.default_rng(gny + gnx).random((len(D), gny, gnx))
+    return mask, edges, bcs, dx, dt, D, bc_diag, bc_src, u0
+
+
+def _oracle_steps(mask, edges, bcs, dx, dt, D, u0, nsteps):
+    ops = O.build_grid_ops(mask, edges, bcs, dx)
+    out = []
+    for k, d in enumerate(D):
+        st = O.ADIStepper(ops, d, dt)
+        g = u0[k].copy()
+        for _ in range(nsteps):
+            g = st.step_grid(g)
+        out.append(g)
+    return np.stack(out)
+
+
+@pytest.mark.parametrize("py,px,gny,gnx", [(1, 2, 64, 192), (2, 1, 192, 70), (2, 2, 128, 200), (1, 3, 5, 256)])
+def test_decomposed_step_sequence_with_virtual_ranks_matches_global_adi(py, px, gny, gnx):
+    mask, edges, bcs, dx, dt, D, bc_diag, bc_src, u0 = _problem(gny, gnx)
+    topos = [BlockTopology(gny, gnx, py, px, r) for r in range(py * px)]
+    blocks = [NumpyBlockBackend(t, dx, dt, D, bc_diag, bc_src) for t in topos]
+    for nsteps in (1, 3):
+        for b in blocks:
+            b.set_field(u0)
+        lockstep_adi_steps(blocks, topos, nsteps)
+        got = np.zeros_like(u0)
+        for b, t in zip(blocks, topos):
+            j0, i0, ny, nx = t.block
+            got[:, j0:j0 + ny, i0:i0 + nx] = b.get_field()
+        want = _oracle_steps(mask, edges, bcs, dx, dt, D, u0, nsteps)
+        assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 1e-12
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _gloo_worker(rank, world, port, py, px, gny, gnx, nsteps, out_dir):
+    for p in (str(ROOT), str(ROOT / "quasiparticle-physics-simulation_amd"), str(ROOT / "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mask, edges, bcs, dx, dt, D, bc_diag, bc_src, u0 = _problem(gny, gnx)
+        topo = BlockTopology(gny, gnx, py, px, rank)
+        be = NumpyBlockBackend(topo, dx, dt, D, bc_diag, bc_src)
+        be.set_field(u0)
+        block_adi_steps(be, topo, TorchDistTransport(), nsteps)
+        np.save(os.path.join(out_dir, f"block_{rank}.npy"), be.get_field())
+        # ensemble mode: independent members, no communication; only a final gather of scalars
+        mine = shard_members(7, world, rank)
+        total = torch.tensor([float(sum(mine))], dtype=torch.float64)
+        dist.all_reduce(total)
+        assert total.item() == sum(range(7))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("py,px", [(1, 2), (2, 1)])
+def test_decomposed_steps_over_gloo_world_size_2(tmp_path, py, px):
+    gny, gnx, nsteps = 128, 192, 2
+    port = _free_port()
+    mp.spawn(_gloo_worker, args=(2, port, py, px, gny, gnx, nsteps, str(tmp_path)), nprocs=2, join=True)
+    mask, edges, bcs, dx, dt, D, bc_diag, bc_src, u0 = _problem(gny, gnx)
+    got = np.zeros_like(u0)
+    for r in range(2):
+        j0, i0, ny, nx = BlockTopology(gny, gnx, py, px, r).block
+        got[:, j0:j0 + ny, i0:i0 + nx] = np.load(tmp_path / f"block_{r}.npy")
+    want = _oracle_steps(mask, edges, bcs, dx, dt, D, u0, nsteps)
+    assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 1e-12

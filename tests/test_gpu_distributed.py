@@ -1,0 +1,87 @@
+"""Domain-decomposed ADI on the GPU: several virtual ranks on one device (lock-step), and two real processes sharing
+the device with gloo as the transport (the RCCL transport differs only in who moves the rows)."""
+from __future__ import annotations
+
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _setup(gny, gnx):
+    from test_distributed_cpu import _problem
+    return _problem(gny, gnx)
+
+
+def _oracle(mask, edges, bcs, dx, dt, D, u0, nsteps):
+    from test_distributed_cpu import _oracle_steps
+    return _oracle_steps(mask, edges, bcs, dx, dt, D, u0, nsteps)
+
+
+@pytest.mark.parametrize("py,px,gny,gnx", [(1, 2, 64, 192), (2, 1, 192, 70), (2, 2, 128, 200), (2, 4, 256, 512), (1, 3, 5, 256)])
+def test_hip_blocks_in_lockstep_match_global_adi(py, px, gny, gnx):
+    from qpsim_amd.distributed import BlockTopology, HipBlockBackend, lockstep_adi_steps
+    mask, edges, bcs, dx, dt, D, bc_diag, bc_src, u0 = _setup(gny, gnx)
+    topos = [BlockTopology(gny, gnx, py, px, r) for r in range(py * px)]
+    blocks = [HipBlockBackend(t, dx, dt, D, bc_diag, bc_src) for t in topos]
+    for nsteps in (1, 3):
+        for b in blocks:
+            b.set_field(u0)
+        lockstep_adi_steps(blocks, topos, nsteps)
+        got = np.zeros_like(u0)
+        for b, t in zip(blocks, topos):
+            j0, i0, ny, nx = t.block
+            got[:, j0:j0 + ny, i0:i0 + nx] = b.get_field()
+        want = _oracle(mask, edges, bcs, dx, dt, D, u0, nsteps)
+        assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 2e-13
+
+
+def test_decomposed_plan_rejects_stiff_coefficients_and_unaligned_blocks():
+    from qpsim_amd import _hip
+    from qpsim_amd.distributed import BlockTopology, HipBlockBackend
+    mask, edges, bcs, dx, dt, D, bc_diag, bc_src, u0 = _setup(128, 128)
+    with pytest.raises(_hip.QPHipError, match="too large for a decomposed grid"):
+        HipBlockBackend(BlockTopology(128, 128, 1, 2, 0), dx, dt, [400.0], bc_diag, bc_src)
+    # 136 rows cut in two leaves an 8-row block: the coupling through it does not underflow
+    with pytest.raises(_hip.QPHipError, match="too large for a decomposed grid"):
+        HipBlockBackend(BlockTopology(136, 128, 2, 1, 0), dx, dt, [6.0], bc_diag, bc_src)
+
+
+def _worker(rank, world, port, py, px, gny, gnx, nsteps, out_dir):
+    for p in (str(ROOT), str(ROOT / "quasiparticle-physics-simulation_amd"), str(ROOT / "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from qpsim_amd.distributed import BlockTopology, HipBlockBackend, TorchDistTransport, block_adi_steps
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mask, edges, bcs, dx, dt, D, bc_diag, bc_src, u0 = _setup(gny, gnx)
+        topo = BlockTopology(gny, gnx, py, px, rank)
+        be = HipBlockBackend(topo, dx, dt, D, bc_diag, bc_src, device="cuda:0")
+        be.set_field(u0)
+        block_adi_steps(be, topo, TorchDistTransport(), nsteps)
+        np.save(os.path.join(out_dir, f"block_{rank}.npy"), be.get_field())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_share_the_gpu_and_exchange_over_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    from qpsim_amd.distributed import BlockTopology
+    from test_distributed_cpu import _free_port
+    py, px, gny, gnx, nsteps = 1, 2, 192, 256, 3
+    mp.spawn(_worker, args=(2, _free_port(), py, px, gny, gnx, nsteps, str(tmp_path)), nprocs=2, join=True)
+    mask, edges, bcs, dx, dt, D, bc_diag, bc_src, u0 = _setup(gny, gnx)
+    got = np.zeros_like(u0)
+    for r in range(2):
+        j0, i0, ny, nx = BlockTopology(gny, gnx, py, px, r).block
+        got[:, j0:j0 + ny, i0:i0 + nx] = np.load(tmp_path / f"block_{r}.npy")
+    want = _oracle(mask, edges, bcs, dx, dt, D, u0, nsteps)
+    assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 2e-13
