@@ -543,7 +543,8 @@ int qp_adi_rect_plan_create_block(int32_t ny, int32_t nx, int32_t nfield, double
   QP_REQUIRE((j0 + ny == gny || ny % TS == 0) && (i0 + nx == gnx || nx % TS == 0),
              "interior block extents must be multiples of 64");
   for (int b = 0; b < nfield; ++b) QP_REQUIRE(dcoef_host[b] >= 0.0, "diffusion coefficients must be >= 0");
-  const bool decomposed = !(gny == ny && gnx == nx);
+  const bool split[2] = {gnx != nx, gny != ny};   // direction d is cut across ranks
+  const bool decomposed = split[0] || split[1];
   QP_REQUIRE(!(decomposed && force_banded), "the banded reduced solve is not available on decomposed grids");
   auto* plan = new qp_adi_rect_plan();
   plan->decomposed = decomposed;
@@ -566,7 +567,7 @@ int qp_adi_rect_plan_create_block(int32_t ny, int32_t nx, int32_t nfield, double
   std::vector<double> lu[2], icoef[2];
   double far[2] = {0.0, 0.0};
   for (int d = 0; d < 2; ++d) {
-    lu[d].assign(decomposed ? 1 : (size_t)nfield * 5 * 2 * spec[d].P, 0.0);
+    lu[d].assign(split[d] ? 1 : (size_t)nfield * 5 * 2 * spec[d].P, 0.0);
     icoef[d].assign((size_t)nfield * (ploc[d] + 1) * 3, 0.0);
   }
   for (int b = 0; b < nfield; ++b) {
@@ -585,15 +586,16 @@ int qp_adi_rect_plan_create_block(int32_t ny, int32_t nx, int32_t nfield, double
         build_chunk_table(spec[d], a, p, &tab[((((size_t)d * nfield + b) * 4 + var) * T_NSLOT) * TS], ends);
       }
       far[d] = std::max(far[d], reduced_tables(spec[d], a, p0[d], ploc[d],
-                                               decomposed ? nullptr : &lu[d][(size_t)b * 5 * 2 * P],
+                                               split[d] ? nullptr : &lu[d][(size_t)b * 5 * 2 * P],
                                                &icoef[d][(size_t)b * (ploc[d] + 1) * 3]));
     }
   }
   for (int d = 0; d < 2; ++d) v.decoupled[d] = (force_banded == 0 && far[d] < kFarCouplingDrop) ? 1 : 0;
-  if (decomposed && !(v.decoupled[0] && v.decoupled[1])) {
+  if ((split[0] && !v.decoupled[0]) || (split[1] && !v.decoupled[1])) {
     delete plan;
     set_error("qp_adi_rect_plan_create_block: r*D too large for a decomposed grid (couplings between 64-cell chunks "
-              "%.3g / %.3g exceed %.0e; the global banded reduced solve is not implemented across ranks)",
+              "along x / y: %.3g / %.3g, limit %.0e; the banded reduced solve is not implemented across ranks; a short "
+              "remainder chunk, n %% 64 < ~40, has the same effect)",
               far[0], far[1], kFarCouplingDrop);
     return QP_ERR_UNSUPPORTED;
   }

@@ -23,7 +23,7 @@ def _oracle(mask, edges, bcs, dx, dt, D, u0, nsteps):
     return _oracle_steps(mask, edges, bcs, dx, dt, D, u0, nsteps)
 
 
-@pytest.mark.parametrize("py,px,gny,gnx", [(1, 2, 64, 192), (2, 1, 192, 70), (2, 2, 128, 200), (2, 4, 256, 512), (1, 3, 5, 256)])
+@pytest.mark.parametrize("py,px,gny,gnx", [(1, 2, 64, 192), (2, 1, 192, 70), (2, 2, 128, 240), (2, 4, 256, 512), (1, 3, 5, 256)])
 def test_hip_blocks_in_lockstep_match_global_adi(py, px, gny, gnx):
     from qpsim_amd.distributed import BlockTopology, HipBlockBackend, lockstep_adi_steps
     mask, edges, bcs, dx, dt, D, bc_diag, bc_src, u0 = _setup(gny, gnx)
