@@ -164,7 +164,66 @@ class CoupledWorkload:
                 "note": f"16*(NE+Nw) B per pixel when phonons are dynamic; ~26*NE^2 = {26 * pairs} flop per pixel-update"}
 
 
+class DecomposedADIWorkload:
+    """BASELINE configs[4]: one N x N scalar field cut into a py x px grid of blocks, one block per rank, neighbour
+    exchange of one reduced-rhs row per sweep over torch.distributed (RCCL).  Strong scaling: the grid is fixed."""
+
+    def __init__(self, N: int, device):
+        import torch.distributed as dist
+        from .distributed import BlockTopology, HipBlockBackend, TorchDistTransport, choose_process_grid
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        py, px = choose_process_grid(self.world, N, N)
+        self.topo = BlockTopology(N, N, py, px, rank)
+        self.be = HipBlockBackend(self.topo, 1.0, 0.1, [6.0], [0.0] * 4, [0.0] * 4, device=device)
+        self.transport = TorchDistTransport() if self.world > 1 else None
+        j0, i0, ny, nx = self.topo.block
+        rng = np.random.default_rng(1000 + rank)
+        self.be.u.copy_(self.be.torch.as_tensor(1e-4 * (1.0 + rng.random((1, ny * nx))), device=self.be.device))
+        self.N, self.nfield, self.grid = N, 1, [N, N]
+        self.cell_updates_per_step = float(N) * N / self.world    # bench multiplies by world
+        self.bytes_per_step = 32.0 * self.cell_updates_per_step
+        self.path = f"rect-tiled partition ADI, {py}x{px} blocks of {ny}x{nx}, point-to-point interface rows"
+        self.description = (f"{N}x{N} fp64 CN-ADI step, domain-decomposed {py}x{px} (one block per GPU), reflective walls, "
+                            "D=6 dt=0.1 dx=1")
+        self.scaling = "strong"
+
+    def run(self, k: int):
+        from .distributed import LocalTransport, block_adi_steps
+        transport = self.transport
+        if transport is None:
+            class _Nop:
+                def exchange(self, sends, recvs):
+                    assert not sends and not recvs
+            transport = _Nop()
+        block_adi_steps(self.be, self.topo, transport, k)
+
+    def roofline(self, nrep: int) -> dict:
+        torch = self.be.torch
+        dev = self.be.device
+        k = 10
+        self.run(2)
+        torch.cuda.synchronize(dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream(dev))
+        for _ in range(nrep):
+            self.run(k)
+        ev1.record(torch.cuda.current_stream(dev))
+        torch.cuda.synchronize(dev)
+        per_sweep = ev0.elapsed_time(ev1) * 1e-3 / (nrep * (2 * k + 1))
+        j0, i0, ny, nx = self.topo.block
+        bytes_per_launch = 16.0 * ny * nx
+        achieved = bytes_per_launch / per_sweep / 1e9
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "kernel": "rect_x_kernel / rect_y_kernel on the local block (rank 0)",
+                "bytes_per_launch": bytes_per_launch, "avg_launch_us": per_sweep * 1e6,
+                "note": "per-rank sweep time including the neighbour exchange that follows it"}
+
+
 def build(name: str, device):
+    m = re.fullmatch(r"dd(\d+)", name)
+    if m:
+        return DecomposedADIWorkload(int(m.group(1)), device)
     m = re.fullmatch(r"adi(\d+)", name)
     if m:
         return ADIWorkload(int(m.group(1)), device)
