@@ -125,6 +125,16 @@ int qp_collision_step(const qp_collision_tables* t, const uint8_t* flags, int64_
                       int enable_recombination, int enable_scattering, int update_phonons, void* stream);
 
 /*
+ * Explicit fixed-bath collision helpers of the reference's step API (not on its time loop; API parity):
+ * rhs = [g_therm - 2 n dE (K_r n)] (if kr) + [dE rho (1-f) (K_s^T n) - n dE ((K_s rho) (1-f))] (if ks), per cell;
+ * out = rhs (rhs_only != 0: solver.py:608-637 _collision_rhs) or max(n + dt rhs, 0) (solver.py:551-605
+ * apply_scattering_step / apply_recombination_step).  state_in, out: [ne][ncell], must not alias.
+ */
+int qp_euler_collision(int32_t ne, int64_t ncell, const double* state_in, double* out, const double* kr,
+                       const double* g_therm, const double* ks, const double* rho, double dE, double dt, int rhs_only,
+                       void* stream);
+
+/*
  * state[f][p] += amount for every interior cell of `nfield` planes (constant / pulse external generation,
  * solver.py:910-916,1464), or state += scale * g[f][p] (custom generation evaluated on the host).
  */

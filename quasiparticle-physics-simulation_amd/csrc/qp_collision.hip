@@ -159,3 +159,54 @@ extern "C" int qp_collision_step(const qp_collision_tables* t, const uint8_t* fl
                      enable_scattering, update_phonons);
   return qp::check_launch("qp_collision_step");
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Explicit (forward-Euler) fixed-bath collision helpers of the reference's public step API
+// (solver.py:551-580 apply_scattering_step, :583-605 apply_recombination_step, :608-637 _collision_rhs).
+// They are not called by the reference's time loop; kept for API parity.  One thread per cell, generic NE.
+// ---------------------------------------------------------------------------------------------------------
+namespace qp {
+
+__global__ void __launch_bounds__(256) euler_collision_kernel(int ne, long ncell, const double* __restrict__ sin_,
+                                                              double* __restrict__ out, const double* __restrict__ kr,
+                                                              const double* __restrict__ g_therm,
+                                                              const double* __restrict__ ks,
+                                                              const double* __restrict__ rho, double dE, double dt,
+                                                              int rhs_only) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= ncell) return;
+  for (int i = 0; i < ne; ++i) {
+    const double ni = sin_[(long)i * ncell + p];
+    double rhs = 0.0;
+    if (kr && g_therm) {
+      double acc = 0.0;
+      for (int j = 0; j < ne; ++j) acc += kr[i * ne + j] * sin_[(long)j * ncell + p];
+      rhs += g_therm[i] - 2.0 * ni * dE * acc;
+    }
+    if (ks && rho) {
+      const double bi = fmax(1.0 - ni / fmax(rho[i], 1e-30), 0.0);
+      double gin = 0.0, gout = 0.0;
+      for (int j = 0; j < ne; ++j) {
+        const double nj = sin_[(long)j * ncell + p];
+        const double bj = fmax(1.0 - nj / fmax(rho[j], 1e-30), 0.0);
+        gin += ks[j * ne + i] * nj;
+        gout += ks[i * ne + j] * rho[j] * bj;
+      }
+      rhs += dE * rho[i] * bi * gin - ni * dE * gout;
+    }
+    out[(long)i * ncell + p] = rhs_only ? rhs : fmax(ni + dt * rhs, 0.0);
+  }
+}
+
+}  // namespace qp
+
+extern "C" int qp_euler_collision(int32_t ne, int64_t ncell, const double* state_in, double* out, const double* kr,
+                                  const double* g_therm, const double* ks, const double* rho, double dE, double dt,
+                                  int rhs_only, void* stream) {
+  QP_REQUIRE(ne > 0 && ncell > 0 && state_in && out && state_in != out, "bad arguments (state_in and out must differ)");
+  QP_REQUIRE((kr == nullptr) == (g_therm == nullptr), "kr and g_therm come together");
+  QP_REQUIRE((ks == nullptr) == (rho == nullptr), "ks and rho come together");
+  hipLaunchKernelGGL(qp::euler_collision_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (int)ne, (long)ncell, state_in, out, kr, g_therm, ks, rho, dE, dt, rhs_only);
+  return qp::check_launch("qp_euler_collision");
+}

@@ -78,6 +78,23 @@ def resolve_phonon_full_custom_spec(spec: InitialConditionSpec):
             dict(spec.phonon_full_custom_params or {}))
 
 
+def canonicalize_initial_condition(spec: InitialConditionSpec) -> InitialConditionSpec:
+    """Spec with every empty kind/body replaced by its default (initial_conditions.py:141-177)."""
+    sk, sp, sb, scp = resolve_spatial_spec(spec)
+    ek, ep, eb, ecp = resolve_energy_spec(spec)
+    pk, pp, pb, pcp = resolve_phonon_spatial_spec(spec)
+    qk, qp, qb, qcp = resolve_phonon_energy_spec(spec)
+    qf_on, qf_body, qf_params = resolve_qp_full_custom_spec(spec)
+    pf_on, pf_body, pf_params = resolve_phonon_full_custom_spec(spec)
+    return InitialConditionSpec(
+        spatial_kind=sk, spatial_params=sp, spatial_custom_body=sb, spatial_custom_params=scp,
+        energy_kind=ek, energy_params=ep, energy_custom_body=eb, energy_custom_params=ecp,
+        qp_full_custom_enabled=bool(qf_on), qp_full_custom_body=qf_body, qp_full_custom_params=qf_params,
+        phonon_spatial_kind=pk, phonon_spatial_params=pp, phonon_spatial_custom_body=pb, phonon_spatial_custom_params=pcp,
+        phonon_energy_kind=qk, phonon_energy_params=qp, phonon_energy_custom_body=qb, phonon_energy_custom_params=qcp,
+        phonon_full_custom_enabled=bool(pf_on), phonon_full_custom_body=pf_body, phonon_full_custom_params=pf_params)
+
+
 def _pixel_centres(mask: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
     """Normalised pixel-centre coordinates x, y in (0, 1) on the full grid."""
     ny, nx = mask.shape

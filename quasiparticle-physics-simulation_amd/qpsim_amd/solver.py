@@ -53,7 +53,8 @@ __all__ = [
     "evaluate_external_generation", "build_energy_grid", "integration_widths_from_centers",
     "thermal_phonon_occupation", "thermal_qp_weights", "recombination_kernel_base", "scattering_kernel_base",
     "recombination_kernel", "scattering_kernel", "apply_collision_step_fischer_catelani_uniform",
-    "apply_collision_step_fischer_catelani_nonuniform",
+    "apply_collision_step_fischer_catelani_nonuniform", "apply_scattering_step", "apply_recombination_step",
+    "build_laplacian_with_boundaries", "build_variable_diffusion_laplacian",
 ]
 
 
@@ -539,6 +540,98 @@ def _collision_step_host(state, phonon_state, kr, ks, rho, idx_diff, idx_sum, si
     state[:, :] = eng.download_packed(s_out)
     if upd:
         phonon_state[:, :] = eng.download_packed(ph)
+
+
+def _euler_call(state2d: np.ndarray, K_r, G_therm, K_s, rho, dE, dt, rhs_only, device=None) -> np.ndarray:
+    import ctypes as C
+    from . import _hip
+    from .engine import require_gpu
+    torch = require_gpu()
+    lib = _hip.load()
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    up = lambda a: None if a is None else torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev)  # noqa: E731
+    s_in = up(state2d)
+    out = torch.empty_like(s_in)
+    kr, g, ks, rh = up(K_r), up(G_therm), up(K_s), up(rho)
+    ptr = lambda t: 0 if t is None else int(t.data_ptr())  # noqa: E731
+    _hip.check(lib.qp_euler_collision(state2d.shape[0], state2d.shape[1], ptr(s_in), ptr(out), ptr(kr), ptr(g), ptr(ks),
+                                      ptr(rh), float(dE), float(dt), int(rhs_only),
+                                      int(torch.cuda.current_stream(dev).cuda_stream)), "qp_euler_collision")
+    return out.cpu().numpy()
+
+
+def apply_scattering_step(state: np.ndarray, K_s: np.ndarray, rho_bins: np.ndarray, dE: float, dt: float) -> None:
+    """One forward-Euler step of fixed-bath scattering, in place on state[NE, n] (solver.py:551-580)."""
+    state[:, :] = _euler_call(state, None, None, K_s, rho_bins, dE, dt, False)
+
+
+def apply_recombination_step(state: np.ndarray, K_r: np.ndarray, G_therm: np.ndarray, dE: float, dt: float) -> None:
+    """One forward-Euler step of recombination + thermal generation, in place (solver.py:583-605)."""
+    state[:, :] = _euler_call(state, K_r, G_therm, None, None, dE, dt, False)
+
+
+def _collision_rhs(n: np.ndarray, K_r, K_s, rho_bins, G_therm, dE: float) -> np.ndarray:
+    """dn/dt of one pixel from recombination (if K_r and G_therm) and scattering (if K_s and rho) (solver.py:608-637)."""
+    use_r = K_r is not None and G_therm is not None
+    use_s = K_s is not None and rho_bins is not None
+    if not (use_r or use_s):
+        return np.zeros_like(n)
+    return _euler_call(np.asarray(n, dtype=float)[:, None], K_r if use_r else None, G_therm if use_r else None,
+                       K_s if use_s else None, rho_bins if use_s else None, dE, 0.0, True)[:, 0]
+
+
+def _mask_to_index(mask: np.ndarray):
+    """index_map[ny, nx] (-1 outside) and interior (row, col) list in argwhere order (solver.py:53-58)."""
+    mask = np.asarray(mask, dtype=bool)
+    index_map = -np.ones(mask.shape, dtype=int)
+    index_map[mask] = np.arange(int(mask.sum()))
+    return index_map, [tuple(map(int, rc)) for rc in np.argwhere(mask)]
+
+
+def _assemble_csr(geom, D):
+    """CSR matrix and source vector of the 5-point operator described by a CompiledGeometry (D scalar or packed [n])."""
+    from scipy import sparse
+    mask = geom.mask
+    n = int(mask.sum())
+    index = -np.ones(mask.shape, dtype=np.int64)
+    index[mask] = np.arange(n)
+    Dg = np.zeros(mask.shape)
+    Dg[mask] = D
+    inv_dx2 = 1.0 / (geom.dx * geom.dx)
+    rows, cols, vals = [], [], []
+    diag = -(geom.ex + geom.ey) * Dg * inv_dx2
+    for bit, (dr, dc) in ((1, (0, -1)), (2, (0, 1)), (4, (-1, 0)), (8, (1, 0))):
+        r, c = np.nonzero((geom.flags & bit) > 0)
+        dp, dq = Dg[r, c], Dg[r + dr, c + dc]
+        w = 2.0 * dp * dq / np.maximum(dp + dq, 1e-30) * inv_dx2
+        rows.append(index[r, c])
+        cols.append(index[r + dr, c + dc])
+        vals.append(w)
+        np.subtract.at(diag, (r, c), w)
+    r, c = np.nonzero(mask)
+    rows.append(index[r, c])
+    cols.append(index[r, c])
+    vals.append(diag[r, c])
+    L = sparse.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)).tocsr()
+    return L, ((geom.sx + geom.sy) * Dg * inv_dx2)[mask], index
+
+
+def build_laplacian_with_boundaries(mask, edges, edge_conditions, dx):
+    """(L csr [n, n] in 1/dx^2 units, source [n], index_map) -- host-side equivalent of solver.py:152-212.
+
+    The GPU path never forms this matrix; the function exists for callers that inspect the operator.
+    """
+    geom = compile_geometry(np.asarray(mask, dtype=bool), edges, edge_conditions, dx)
+    L, src, index = _assemble_csr(geom, 1.0)
+    index_map = np.where(geom.mask, index, -1).astype(int)
+    return L, src, index_map
+
+
+def build_variable_diffusion_laplacian(mask, edges, edge_conditions, dx, D_spatial):
+    """(L_D csr, source) with harmonic-mean face diffusivities (host-side equivalent of solver.py:235-321)."""
+    geom = compile_geometry(np.asarray(mask, dtype=bool), edges, edge_conditions, dx)
+    L, src, _ = _assemble_csr(geom, np.asarray(D_spatial, dtype=float))
+    return L, src
 
 
 def apply_collision_step_fischer_catelani_uniform(state, phonon_state, K_r0, K_s0, rho_bins, omega_idx_diff,

@@ -444,3 +444,36 @@ def test_merged_phonon_bins_fall_back_to_generic_kernel():
     om, idx_d, idx_s, sg = T.build_phonon_frequency_map(E)
     d, a = structured_bin_maps(idx_d, idx_s, sg)
     assert om.size == 35 and d.size == 12 and a.size == 23
+
+
+def test_euler_step_helpers_match_reference_vectors():
+    """Public explicit-Euler helpers (solver.py:551-637) on the GPU vs recorded reference outputs."""
+    from qpsim_amd import tables as T
+    from qpsim_amd.solver import _collision_rhs, apply_recombination_step, apply_scattering_step
+    z = np.load(GOLDEN / "collision_vectors.npz", allow_pickle=False)
+    E, dE = T.build_energy_grid(180.0, 1.0, 3.0, 8)
+    rho = T.dynes_density_of_states(E, 180.0, 0.0)
+    K_s, K_r = T.scattering_kernel(E, 180.0, 400.0, 1.2, 0.2), T.recombination_kernel(E, 180.0, 500.0, 1.2, 0.2)
+    a = z["euler_state_in"].copy()
+    apply_scattering_step(a, K_s, rho, dE, 0.05)
+    b = z["euler_state_in"].copy()
+    apply_recombination_step(b, K_r, z["euler_G"], dE, 0.05)
+    assert rel_err(a, z["euler_scat_out"]) < 1e-13 and rel_err(b, z["euler_recomb_out"]) < 1e-13
+    assert rel_err(_collision_rhs(z["euler_state_in"][:, 0], K_r, K_s, rho, z["euler_G"], dE), z["euler_rhs_px0"]) < 1e-12
+    assert np.array_equal(_collision_rhs(z["euler_state_in"][:, 0], None, None, None, None, dE), np.zeros(8))
+
+
+def test_fast_validation_suite_on_gpu_matches_reference_report():
+    """tests/test_physics_safety.py:109-117 + the reference's recorded report values."""
+    from qpsim_amd.validation import run_fast_validation_suite
+    ref = json.loads((GOLDEN / "validation_report.json").read_text())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rep = run_fast_validation_suite().as_dict()
+    assert rep["overall_passed"] is True
+    for key in ("detailed_balance", "thermal_stability", "pure_diffusion", "pure_scattering", "pure_recombination"):
+        assert rep[key]["passed"] is True
+    assert rep["detailed_balance"]["max_relative_error"] == ref["detailed_balance"]["max_relative_error"]
+    assert abs(rep["pure_scattering"]["mass_relative_drift"] - ref["pure_scattering"]["mass_relative_drift"]) < 1e-9
+    assert abs(rep["pure_recombination"]["mass_end"] - ref["pure_recombination"]["mass_end"]) < 1e-14
+    assert rep["thermal_stability"]["max_relative_drift"] < 1e-9 and rep["pure_diffusion"]["mass_relative_drift"] < 1e-12

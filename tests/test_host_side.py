@@ -155,3 +155,23 @@ def test_initial_condition_builders_match_reference():
     assert np.array_equal(ic.evaluate_gap_expression("", mask, 180.0), z["gap_values_default"])
     with pytest.raises(ValueError):
         ic.evaluate_gap_expression("return x - 0.5", mask, 180.0)
+
+
+def test_host_operator_assembly_matches_reference_matrices():
+    from golden_utils import bcs_from_json
+    from qpsim_amd.solver import _mask_to_index, build_laplacian_with_boundaries, build_variable_diffusion_laplacian
+    z, meta = _z("operators.npz")
+    edges, bcs = edges_from_json(meta["edges"]), bcs_from_json(meta["edge_conditions"])
+    L, src, index_map = build_laplacian_with_boundaries(z["mask"], edges, bcs, meta["dx"])
+    assert np.allclose(L.toarray(), z["L"], rtol=1e-14, atol=1e-14) and np.allclose(src, z["source"], rtol=1e-14, atol=1e-14)
+    assert np.array_equal(index_map, z["index_map"]) and np.array_equal(_mask_to_index(z["mask"])[0], z["index_map"])
+    LD, srcD = build_variable_diffusion_laplacian(z["mask"], edges, bcs, meta["dx"], z["D_spatial"])
+    assert np.allclose(LD.toarray(), z["L_D"], rtol=1e-14, atol=1e-14) and np.allclose(srcD, z["source_D"], rtol=1e-14, atol=1e-14)
+
+
+def test_canonicalize_initial_condition_fills_defaults():
+    c = ic.canonicalize_initial_condition(InitialConditionSpec())
+    assert (c.spatial_kind, c.energy_kind, c.phonon_spatial_kind, c.phonon_energy_kind) == ("gaussian", "dos", "uniform", "bose_einstein")
+    assert c.spatial_params == {"amplitude": 1.0, "x0": 0.5, "y0": 0.5, "sigma": 0.12} and c.phonon_spatial_params == {"value": 1.0}
+    d = ic.canonicalize_initial_condition(InitialConditionSpec(spatial_kind=" Uniform ", spatial_params={"value": 2.0}))
+    assert d.spatial_kind == "uniform" and d.spatial_params == {"value": 2.0}
