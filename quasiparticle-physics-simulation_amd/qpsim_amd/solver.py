@@ -148,6 +148,19 @@ def evaluate_external_generation(spec: ExternalGenerationSpec, E_bins: np.ndarra
     return checked(out)
 
 
+def _crop_to_bounding_box(mask: np.ndarray, edges: list[EdgeSegment]):
+    """(mask, edges) restricted to the bounding box of the interior cells; faces are re-indexed, ids kept."""
+    rows = np.flatnonzero(mask.any(axis=1))
+    cols = np.flatnonzero(mask.any(axis=0))
+    r0, r1, c0, c1 = int(rows[0]), int(rows[-1]) + 1, int(cols[0]), int(cols[-1]) + 1
+    if (r0, c0) == (0, 0) and (r1, c1) == mask.shape:
+        return mask, edges
+    from .models import BoundaryFace
+    shifted = [EdgeSegment(e.edge_id, e.x0 - c0, e.y0 - r0, e.x1 - c0, e.y1 - r0, e.normal,
+                           [BoundaryFace(f.row - r0, f.col - c0, f.direction) for f in e.faces]) for e in edges]
+    return np.ascontiguousarray(mask[r0:r1, c0:c1]), shifted
+
+
 def _step_plan(total_time: float, dt: float) -> tuple[int, float, int]:
     """(full steps, remainder dt or 0, total steps) (solver.py:1085-1089)."""
     full = int(np.floor(total_time / dt + 1e-12))
@@ -266,12 +279,17 @@ def run_2d_crank_nicolson(
     if external_generation is not None:
         external_generation.validate()
 
+    # Device grid = bounding box of the mask.  Interior cells keep their argwhere (row-major) order under the crop, so
+    # the packed [NE, n] layout of every host-side array is unchanged; frames are still rebuilt on the full mask.  A
+    # mask whose interior is a solid rectangle inside a padded frame (the reference's built-in geometry) thereby
+    # becomes a full rectangle on the device and takes the tiled ADI path.
+    dev_mask, dev_edges = _crop_to_bounding_box(mask, edges)
     if enable_diffusion:
-        geom = compile_geometry(mask, edges, edge_conditions, dx)
+        geom = compile_geometry(dev_mask, dev_edges, edge_conditions, dx)
     else:  # no operator needed: boundary conditions are not consulted (solver.py:1081-1083)
         from .engine import CompiledGeometry, link_flags
-        z = np.zeros(mask.shape)
-        geom = CompiledGeometry(mask, float(dx), link_flags(mask), z, z, z, z)
+        z = np.zeros(dev_mask.shape)
+        geom = CompiledGeometry(dev_mask, float(dx), link_flags(dev_mask), z, z, z, z)
     full_steps, rem, total_steps = _step_plan(total_time, dt)
     eng = Engine(geom, device=device)
     stored = lambda step: step % store_every == 0 or step == total_steps  # noqa: E731

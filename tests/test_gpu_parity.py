@@ -477,3 +477,30 @@ def test_fast_validation_suite_on_gpu_matches_reference_report():
     assert abs(rep["pure_scattering"]["mass_relative_drift"] - ref["pure_scattering"]["mass_relative_drift"]) < 1e-9
     assert abs(rep["pure_recombination"]["mass_end"] - ref["pure_recombination"]["mass_end"]) < 1e-14
     assert rep["thermal_stability"]["max_relative_drift"] < 1e-9 and rep["pure_diffusion"]["mass_relative_drift"] < 1e-12
+
+
+def test_padded_rectangle_geometry_is_cropped_onto_the_fast_path(O):
+    """The reference's built-in geometry (solid rectangle in a padded frame, geometry.py:245-262) must give the same
+    result as the general masked path, and its packed ordering must survive the crop."""
+    from qpsim_amd.engine import Engine
+    from qpsim_amd.geometry import create_intrinsic_geometry, extract_edge_segments
+    from qpsim_amd.models import BoundaryCondition
+    from qpsim_amd.solver import _crop_to_bounding_box, run_2d_crank_nicolson
+    g = create_intrinsic_geometry(width=40, height=28)
+    mask = np.asarray(g.mask, dtype=bool)
+    edges = g.edges
+    kinds = {"left": BoundaryCondition("dirichlet", 0.2), "right": BoundaryCondition("absorbing"),
+             "up": BoundaryCondition("reflective"), "down": BoundaryCondition("robin", 0.3, 0.05)}
+    bcs = {e.edge_id: kinds[e.normal] for e in edges}
+    cm, ce = _crop_to_bounding_box(mask, edges)
+    assert cm.all() and cm.shape == (12, 24) and [e.edge_id for e in ce] == [e.edge_id for e in edges]
+    init = np.random.default_rng(4).random(mask.shape)
+    kw = dict(mask=mask, edges=edges, edge_conditions=bcs, initial_field=init, diffusion_coefficient=3.0, dt=0.1,
+              total_time=0.6, dx=1.0, store_every=3)
+    got = run_2d_crank_nicolson(**kw, diffusion_scheme="adi")
+    ref = O.run(**kw, scheme="adi")
+    assert rel_err(np.stack(got[1]), np.stack(ref[1])) < 1e-12
+    got = run_2d_crank_nicolson(**kw)
+    ref = O.run(**kw, scheme="cn")
+    assert rel_err(np.stack(got[1]), np.stack(ref[1])) < 1e-10
+    assert np.allclose(got[2], ref[2], rtol=1e-10)
