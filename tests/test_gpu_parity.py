@@ -493,7 +493,7 @@ def test_padded_rectangle_geometry_is_cropped_onto_the_fast_path(O):
              "up": BoundaryCondition("reflective"), "down": BoundaryCondition("robin", 0.3, 0.05)}
     bcs = {e.edge_id: kinds[e.normal] for e in edges}
     cm, ce = _crop_to_bounding_box(mask, edges)
-    assert cm.all() and cm.shape == (12, 24) and [e.edge_id for e in ce] == [e.edge_id for e in edges]
+    assert cm.all() and cm.shape == (14, 24) and [e.edge_id for e in ce] == [e.edge_id for e in edges]
     init = np.random.default_rng(4).random(mask.shape)
     kw = dict(mask=mask, edges=edges, edge_conditions=bcs, initial_field=init, diffusion_coefficient=3.0, dt=0.1,
               total_time=0.6, dx=1.0, store_every=3)
