@@ -12,6 +12,10 @@ Workloads (``--workload``):
   c2                 1024 x 1024, NE=12, recombination on, phonons frozen: Strang C(dt/2) D(dt) C(dt/2) per step
                      (BASELINE configs[1]); cell-updates count NE diffusion updates per pixel per step.
   c3                 4096 x 4096, NE=12, recombination + scattering with dynamic phonons (BASELINE configs[2]).
+  c4                 64 independent 256 x 256 MKID pixels per GPU, NE=12, full physics (BASELINE configs[3] is 512
+                     members over 8 GPUs; members never communicate, so --gpus N runs 64 N members).
+  dd<N>              one N x N scalar field domain-decomposed over the ranks (BASELINE configs[4] = dd8192 at 8 GPUs),
+                     neighbour exchange of interface rows over RCCL; "scaling": "strong".
 
 Multi-GPU: independent problems per rank (ensemble sharding, no data-path collective) -> "scaling": "weak".
 """
@@ -144,7 +148,7 @@ def main():
         "hbm_frac_of_step": (wl.bytes_per_step * args.steps / elapsed / 1e9) / HBM_PEAK_GBS,
     }
     if hasattr(wl, "coll_bytes_per_call"):
-        result["pixel_steps_per_s"] = wl.N * wl.N * world * args.steps / elapsed
+        result["pixel_steps_per_s"] = wl.npix * world * args.steps / elapsed
     if rank == 0:
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, args.workload)

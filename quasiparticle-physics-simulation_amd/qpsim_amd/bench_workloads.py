@@ -95,8 +95,11 @@ class CoupledWorkload:
     c2: N = 1024, recombination only, phonons frozen.  c3: N = 4096, recombination + scattering, dynamic phonons.
     """
 
-    def __init__(self, N, device, *, ne=12, recombination=True, scattering=True, dynamic_phonons=True, label=""):
-        self.N, self.nfield, self.ne = N, ne, ne
+    def __init__(self, N, device, *, ne=12, recombination=True, scattering=True, dynamic_phonons=True, label="",
+                 members=1):
+        """``members`` independent N x N problems are batched: planes are laid out [bin][member][cell], so the ADI plan
+        sees NE*members fields of N x N and the collision kernel sees members*N*N pixels (no coupling between members)."""
+        self.N, self.nfield, self.ne, self.members = N, ne * members, ne, members
         self.eng = eng = _rect_engine(N, device)
         torch = eng.torch
         gap, D0, dt = 180.0, 6.0, 0.1
@@ -111,34 +114,63 @@ class CoupledWorkload:
         self.tab = eng.make_collision_tables(kr, ks, rho[None], idx_d, idx_s, sg)
         self.en_r, self.en_s, self.upd = recombination, scattering, dynamic_phonons
         w = rho / (np.sum(rho) * dE)
-        init = 1e-4 * (1.0 + np.random.default_rng(0).random(N * N))
-        self.state = torch.as_tensor(w[:, None] * init[None, :], device=eng.device)
+        npix = members * N * N
+        self.npix = npix
+        init = np.concatenate([1e-4 * (1.0 + np.random.default_rng(1000 + m if members > 1 else 0).random(N * N))
+                               for m in range(members)])
+        self.state = torch.as_tensor(w[:, None] * init[None, :], device=eng.device)     # [NE][members*ncell]
         self.alt = torch.empty_like(self.state)
         nph = T.thermal_phonon_occupation(om, 0.1)
-        self.phonon = torch.as_tensor(np.repeat(nph[:, None], N * N, axis=1), device=eng.device)
-        self.op = DiffusionOperator(eng, ne, dt, dcoef=T.diffusion_coefficients(E, gap, D0))
+        self.phonon = torch.as_tensor(np.repeat(nph[:, None], npix, axis=1), device=eng.device)
+        self.coll_flags = torch.full((npix,), 16, dtype=torch.uint8, device=eng.device)   # every pixel interior
+        self.op = DiffusionOperator(eng, ne * members, dt,
+                                    dcoef=np.repeat(T.diffusion_coefficients(E, gap, D0), members))
         self.grid = [N, N]
-        self.cell_updates_per_step = float(N) * N * ne
+        self.cell_updates_per_step = float(N) * N * ne * members
         planes_rw = (ne + self.nw) + (ne + (self.nw if dynamic_phonons else 0))
-        self.coll_bytes_per_call = 8.0 * planes_rw * N * N
+        self.coll_bytes_per_call = 8.0 * planes_rw * npix
         self.bytes_per_step = 48.0 * self.cell_updates_per_step + 2 * self.coll_bytes_per_call
         self.path = ("rect-tiled ADI + " + ("diagonal register collision kernel" if self.tab["fast"] else "generic collision kernel"))
-        self.description = (f"{label}{N}x{N} fp64, NE={ne}, Nw={self.nw}: Strang C(dt/2) D(dt) C(dt/2) + Pauli guard per step; "
+        ens = f"{members} independent members of " if members > 1 else ""
+        self.description = (f"{label}{ens}{N}x{N} fp64, NE={ne}, Nw={self.nw}: Strang C(dt/2) D(dt) C(dt/2) + Pauli guard per step; "
                             f"recombination={'on' if recombination else 'off'}, scattering={'on' if scattering else 'off'}, "
                             f"phonons {'dynamic' if dynamic_phonons else 'frozen'}; reflective walls, D0=6 dt=0.1 dx=1")
         self.max_occ = 0.0
 
     def _collide(self, dtc):
-        self.eng.collide(self.tab, self.state, self.alt, self.phonon, self.dE, dtc, self.en_r, self.en_s, self.upd)
+        import ctypes as C
+        from . import _hip
+        eng = self.eng
+        acc = None
+        if self.upd and not self.tab["fast"]:
+            acc = eng.scratch("coll_acc", 2 * self.tab["nw"] * self.npix)
+        _hip.check(eng.lib.qp_collision_step(C.byref(self.tab["struct"]), int(self.coll_flags.data_ptr()), self.npix,
+                                             int(self.state.data_ptr()), int(self.alt.data_ptr()),
+                                             int(self.phonon.data_ptr()), 0 if acc is None else int(acc.data_ptr()),
+                                             float(self.dE), float(dtc), int(self.en_r), int(self.en_s), int(self.upd),
+                                             eng.stream), "qp_collision_step")
         self.state, self.alt = self.alt, self.state
+
+    def _guard(self):
+        """Pauli guard over all members (device reduction, result read back on the host as the reference does)."""
+        import ctypes as C
+        from . import _hip
+        eng = self.eng
+        _hip.check(eng.lib.qp_pauli_stats(int(self.state.data_ptr()), int(self.tab["rho"].data_ptr()), 0,
+                                          int(self.coll_flags.data_ptr()), self.ne, 1, self.npix, 1e-18,
+                                          int(eng._ws.data_ptr()), int(eng._red_vals.data_ptr()),
+                                          int(eng._red_idx.data_ptr()), eng.stream), "qp_pauli_stats")
+        mx = float(eng._red_vals[0].item())
+        forb = int(eng._red_idx[1].item())
+        return mx, forb
 
     def run(self, k: int):
         for _ in range(k):
             self._collide(0.5 * self.dt)
             self.eng.adi_steps(self.op, self.state, 1)
             self._collide(0.5 * self.dt)
-            mx, _, forb = self.eng.pauli_stats(self.state, self.tab, 1e-18)   # host reads it back, as the reference does
-            if forb is not None or mx > 1.0:
+            mx, forb = self._guard()
+            if forb >= 0 or mx > 1.0:
                 raise ValueError("Pauli guard tripped in the benchmark state")
             self.max_occ = max(self.max_occ, mx)
 
@@ -160,7 +192,7 @@ class CoupledWorkload:
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None, "kernel": "collision_diag_kernel" if self.tab["fast"] else "collision_generic_kernel",
                 "bytes_per_launch": self.coll_bytes_per_call, "avg_launch_us": per_call * 1e6,
-                "pixel_updates_per_s": self.N * self.N / per_call,
+                "pixel_updates_per_s": self.npix / per_call,
                 "note": f"16*(NE+Nw) B per pixel when phonons are dynamic; ~26*NE^2 = {26 * pairs} flop per pixel-update"}
 
 
@@ -233,6 +265,9 @@ def build(name: str, device):
     if name == "c2":
         return CoupledWorkload(1024, device, recombination=True, scattering=False, dynamic_phonons=False,
                                label="BASELINE configs[1]: ")
+    if name == "c4":   # BASELINE configs[3]: 512 members over 8 GPUs -> 64 independent 256^2 pixels-arrays per GPU
+        return CoupledWorkload(256, device, recombination=True, scattering=True, dynamic_phonons=True, members=64,
+                               label="BASELINE configs[3] (per-GPU share, 64 of 512 members): ")
     if name == "c3":
         return CoupledWorkload(4096, device, recombination=True, scattering=True, dynamic_phonons=True,
                                label="BASELINE configs[2]: ")

@@ -504,3 +504,20 @@ def test_padded_rectangle_geometry_is_cropped_onto_the_fast_path(O):
     ref = O.run(**kw, scheme="cn")
     assert rel_err(np.stack(got[1]), np.stack(ref[1])) < 1e-10
     assert np.allclose(got[2], ref[2], rtol=1e-10)
+
+
+def test_energy_integral_and_weighted_sum_kernels():
+    """qp_energy_integrate / qp_weighted_sum (solver.py:1358,1367,1480) vs NumPy on a masked grid."""
+    from qpsim_amd.engine import CompiledGeometry, Engine, link_flags
+    rng = np.random.default_rng(9)
+    mask = rng.random((13, 17)) > 0.3
+    z = np.zeros(mask.shape)
+    eng = Engine(CompiledGeometry(mask, 1.0, link_flags(mask), z, z, z, z))
+    n = int(mask.sum())
+    state = rng.random((7, n))
+    w = rng.random(7)
+    d = eng.upload_packed(state)
+    got = eng.energy_integral(d, 0.37).cpu().numpy()[mask.reshape(-1)]
+    assert np.array_equal(got, np.sum(state, axis=0) * 0.37)      # same sequential order as np.sum(axis=0)
+    got = eng.weighted_sum(d, w).cpu().numpy()[mask.reshape(-1)]
+    assert rel_err(got, np.sum(state * w[:, None], axis=0)) < 1e-15
