@@ -189,6 +189,9 @@ int qp_adi_rect_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, co
 int qp_adi_rect_plan_destroy(qp_adi_rect_plan* plan);
 int qp_adi_rect_plan_decoupled(const qp_adi_rect_plan* plan, int32_t dir);
 int qp_adi_rect_steps(qp_adi_rect_plan* plan, double* u, int32_t nsteps, void* stream);
+/* x[nfield][ny*nx] <- (I - a Ly)^-1 (I - a Lx)^-1 x in place: the ADI factorisation applied as the preconditioner of
+ * the exact Crank-Nicolson iteration (replaces two qp_implicit_sweep calls on full rectangles). */
+int qp_adi_rect_solve(qp_adi_rect_plan* plan, double* x, void* stream);
 
 /*
  * Domain decomposition (one rank per GPU owns a ny x nx block at offset (j0, i0) of a gny x gnx grid; offsets and

@@ -248,6 +248,8 @@ __device__ __forceinline__ void chunk_ghosts(const RectView& v, int b, int p, lo
 // ---------------------------------------------------------------------------------------------------------
 // x-kernel: finish the x-solve, apply the explicit x-operator, eliminate along y.   buf: rhs1 -> rhs2 in place
 // ---------------------------------------------------------------------------------------------------------
+// EXPLICIT = false is the plain solve (I - a Lx)^-1 used by the exact-CN preconditioner: no explicit operator, no sources.
+template <bool EXPLICIT>
 __global__ void __launch_bounds__(64) rect_x_kernel(RectView v, double* __restrict__ buf) {
   __shared__ double lds[LDS_DOUBLES];
   const int lane = threadIdx.x;
@@ -270,7 +272,7 @@ __global__ void __launch_bounds__(64) rect_x_kernel(RectView v, double* __restri
   double srow = 0.0;                   // sources of the y-faces (up/down) belong to rows 0 and ny-1
   if (row + v.d.j0 == 0) srow += a * v.other_src[1][0];
   if (row + v.d.j0 == v.d.gny - 1) srow += a * v.other_src[1][1];
-  explicit64(e, gl, gr, tx_tab, row_on ? srow : 0.0);
+  if (EXPLICIT) explicit64(e, gl, gr, tx_tab, row_on ? srow : 0.0);
   transpose64(e, lds, lane);
   // lane = column again
   store_cols(plane, t, v.d.nx, lane, e);
@@ -287,6 +289,7 @@ __global__ void __launch_bounds__(64) rect_x_kernel(RectView v, double* __restri
 // y-kernel.  MODE 0 (entry): src = u, no solve, halo rows from u;  dst = rhs1, x-elimination
 //            MODE 1 (carry): src = rhs2, y-solve, rhs1' = (I + a Ly) u' + a S; dst = rhs1', x-elimination
 //            MODE 2 (exit):  src = rhs2, y-solve, dst = u'
+//            MODE 3 (reduce): src = rhs of an x-solve; only its reduced right-hand sides are formed (nothing stored)
 // ---------------------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ void __launch_bounds__(64) rect_y_kernel(RectView v, const double* src, double* dst) {  // src may alias dst
@@ -303,7 +306,9 @@ __global__ void __launch_bounds__(64) rect_y_kernel(RectView v, const double* sr
   double e[TS];
   load_cols(splane, t, v.d.nx, lane, e);
   double gu = 0.0, gd = 0.0;           // values of the field just above / below the tile
-  if (MODE == 0) {
+  if (MODE == 3) {
+    // nothing to solve or apply: fall through to the x-elimination
+  } else if (MODE == 0) {
     if (col_on) {
       if (t.ty > 0) gu = splane[(long)(t.j0 - 1) * v.d.nx + col];
       else if (v.d.j0 > 0) gu = v.uhalo[0][(long)t.b * v.d.nx + col];                 // row owned by the rank above
@@ -323,8 +328,10 @@ __global__ void __launch_bounds__(64) rect_y_kernel(RectView v, const double* sr
   double scol = 0.0;                   // sources of the x-faces (left/right) belong to columns 0 and nx-1
   if (col + v.d.i0 == 0) scol += a * v.other_src[0][0];
   if (col + v.d.i0 == v.d.gnx - 1) scol += a * v.other_src[0][1];
-  explicit64(e, gu, gd, ty_tab, col_on ? scol : 0.0);
-  store_cols(dplane, t, v.d.nx, lane, e);
+  if (MODE != 3) {
+    explicit64(e, gu, gd, ty_tab, col_on ? scol : 0.0);
+    store_cols(dplane, t, v.d.nx, lane, e);
+  }
   transpose64(e, lds, lane);
   double yf, yl;
   dots64(e, table_ptr(v, 0, t.b, chunk_variant(t.tx + v.d.i0 / TS, v.d.gpx)), yf, yl);
@@ -663,7 +670,7 @@ int qp_adi_rect_phase(qp_adi_rect_plan* plan, int32_t phase, double* u, void* st
                            stream, v, 0);
       break;
     case QP_ADI_SWEEP_X:
-      hipLaunchKernelGGL(rect_x_kernel, dim3(tiles), dim3(64), 0, stream, v, w);
+      hipLaunchKernelGGL(rect_x_kernel<true>, dim3(tiles), dim3(64), 0, stream, v, w);
       break;
     case QP_ADI_REDUCED_Y:
       if (!v.decoupled[1])
@@ -696,6 +703,25 @@ int qp_adi_rect_steps(qp_adi_rect_plan* plan, double* u, int32_t nsteps, void* s
     if (rc == QP_OK) rc = qp_adi_rect_phase(plan, s + 1 < nsteps ? QP_ADI_SWEEP_Y_CARRY : QP_ADI_SWEEP_Y_EXIT, u, stream);
   }
   return rc;
+}
+
+// x <- (I - a Ly)^-1 (I - a Lx)^-1 x in place, per field: the ADI factorisation M of the Crank-Nicolson matrix
+// A = I - a (Lx + Ly), applied as a preconditioner (no explicit operators, no boundary sources).  Three passes.
+int qp_adi_rect_solve(qp_adi_rect_plan* plan, double* x, void* stream_) {
+  QP_REQUIRE(plan && x, "plan and x must be non-NULL");
+  QP_REQUIRE(!plan->decomposed, "qp_adi_rect_solve is not available on decomposed plans");
+  using namespace qp;
+  hipStream_t stream = (hipStream_t)stream_;
+  const RectView& v = plan->view;
+  const unsigned tiles = (unsigned)((long)v.d.nfield * v.d.py * v.d.px);
+  hipLaunchKernelGGL(rect_y_kernel<3>, dim3(tiles), dim3(64), 0, stream, v, (const double*)x, x);
+  int rc = qp_adi_rect_phase(plan, QP_ADI_REDUCED_X, x, stream_);
+  if (rc) return rc;
+  hipLaunchKernelGGL(rect_x_kernel<false>, dim3(tiles), dim3(64), 0, stream, v, x);
+  rc = qp_adi_rect_phase(plan, QP_ADI_REDUCED_Y, x, stream_);
+  if (rc) return rc;
+  hipLaunchKernelGGL(rect_y_kernel<2>, dim3(tiles), dim3(64), 0, stream, v, (const double*)x, x);
+  return check_launch("qp_adi_rect_solve");
 }
 
 // Boundary rows of the reduced right-hand sides <-> contiguous [nfield][nlines] buffers (domain decomposition).

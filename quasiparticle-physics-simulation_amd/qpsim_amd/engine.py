@@ -361,8 +361,11 @@ class Engine:
                 raise FloatingPointError("exact-CN iteration diverged (non-finite residual)")
             if err <= rtol * scale or its >= max_iter:
                 break
-            self.sweep(op, 0, res, res)
-            self.sweep(op, 1, res, res)
+            if op.rect is not None:
+                _hip.check(self.lib.qp_adi_rect_solve(op.rect.handle, _ptr(res), self.stream), "qp_adi_rect_solve")
+            else:
+                self.sweep(op, 0, res, res)
+                self.sweep(op, 1, res, res)
             _hip.check(self.lib.qp_axpy(n, 1.0, _ptr(res), _ptr(v), self.stream), "qp_axpy")
             its += 1
         u.copy_(v)

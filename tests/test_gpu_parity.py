@@ -375,6 +375,32 @@ def test_rect_fast_path_matches_oracle_adi_and_general_kernels(O, ny, nx):
             assert rel_err(hb[k], want) < 2e-13, (k, nsteps)
 
 
+@pytest.mark.parametrize("ny,nx,D", [(64, 64, 6.0), (70, 130, 2.0), (128, 192, 40.0), (1, 100, 6.0)])
+def test_exact_cn_iteration_on_the_fast_path_matches_superlu(O, ny, nx, D):
+    """Exact-CN step whose preconditioner runs on the tiled solve (decoupled and banded regimes) vs the oracle's SuperLU."""
+    from qpsim_amd.engine import DiffusionOperator, Engine, compile_geometry
+    from qpsim_amd.geometry import extract_edge_segments
+    from qpsim_amd.models import BoundaryCondition
+    rng = np.random.default_rng(ny + nx)
+    mask = np.ones((ny, nx), dtype=bool)
+    edges = extract_edge_segments(mask)
+    side_bc = {"left": BoundaryCondition("dirichlet", 0.7), "right": BoundaryCondition("robin", 0.4, 0.2),
+               "up": BoundaryCondition("neumann", -0.3), "down": BoundaryCondition("absorbing")}
+    bcs = {e.edge_id: side_bc[e.normal] for e in edges}
+    dx, dt = 0.9, 0.11
+    eng = Engine(compile_geometry(mask, edges, bcs, dx))
+    op = DiffusionOperator(eng, 2, dt, dcoef=[D, 0.5 * D])
+    assert op.rect is not None
+    u0 = rng.random((2, ny * nx))
+    v = eng.upload_packed(u0)
+    its = eng.cn_exact_step(op, v)
+    ops = O.build_grid_ops(mask, edges, bcs, dx)
+    got = eng.download_packed(v)
+    for k, d in enumerate([D, 0.5 * D]):
+        assert rel_err(got[k], O.CNStepper(ops, d, dt).step(u0[k])) < 1e-11
+    assert its <= 60 and (ny > 1 or its == 0)
+
+
 def test_rect_fast_path_large_reflective_conserves_mass_and_matches_general():
     """4096-class property check at a size the oracle cannot reach quickly: 1024^2, 5 steps, reflective walls."""
     from qpsim_amd.engine import DiffusionOperator, Engine, compile_geometry
