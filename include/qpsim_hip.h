@@ -111,7 +111,13 @@ typedef struct qp_collision_tables {
    * ph_scratch unused).  NULL selects the generic table-driven kernel. */
   const int32_t* diag_bin; /* [ne] or NULL */
   const int32_t* anti_bin; /* [2*ne-1] or NULL */
+  /* Kernel selection.  Default (0): register-resident kernel when (diag_bin, nclass == 1, ne <= 16); otherwise, for
+   * ne <= 64, one wave per pixel with lanes <-> energy bins (deterministic when diag_bin vouches for the bin-map structure,
+   * LDS atomics otherwise); otherwise the generic one-thread-per-cell kernel.  The FORCE bits exist for tests. */
+  uint32_t flags;
 } qp_collision_tables;
+#define QP_COLL_FORCE_GENERIC 1u
+#define QP_COLL_FORCE_WAVE 2u
 
 /*
  * One local coupled quasiparticle-phonon collision update of every interior cell

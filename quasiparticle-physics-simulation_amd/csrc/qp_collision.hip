@@ -130,6 +130,20 @@ bool collision_fast_dispatch(int ne, const double* kr0, const double* ks0, const
                              const int* anti_bin, const uint8_t* flags, long ncell, const double* sin_, double* sout,
                              double* ph, double dE, double dt, int en_r, int en_s, int upd, hipStream_t stream);
 
+struct WaveCollView {
+  int ne, nw, nclass;
+  const double* kr0;
+  const double* ks0;
+  const double* rho;
+  const int32_t* idx_diff;
+  const int32_t* idx_sum;
+  const int8_t* sign;
+  const int32_t* cls;
+};
+bool collision_wave_dispatch(const WaveCollView& v, bool structured, const uint8_t* flags, long ncell, const double* sin_,
+                             double* sout, double* ph, double dE, double dt, int en_r, int en_s, int upd,
+                             hipStream_t stream);
+
 }  // namespace qp
 
 extern "C" int qp_collision_step(const qp_collision_tables* t, const uint8_t* flags, int64_t ncell,
@@ -143,15 +157,22 @@ extern "C" int qp_collision_step(const qp_collision_tables* t, const uint8_t* fl
   QP_REQUIRE(flags && state_in && state_out && phonon, "flags, state_in, state_out, phonon must be non-NULL");
   QP_REQUIRE(state_in != state_out, "state_in and state_out must not alias");
   QP_REQUIRE(ncell > 0, "ncell must be positive");
-  const bool fast_ok = t->diag_bin && t->anti_bin && t->nclass == 1 && t->ne >= 2 && t->ne <= 16;
-  QP_REQUIRE(!(update_phonons && (enable_recombination || enable_scattering)) || ph_scratch || fast_ok,
+  const bool no_scratch_ok = !(t->flags & QP_COLL_FORCE_GENERIC) && t->ne <= 64 && t->nw <= 192;
+  QP_REQUIRE(!(update_phonons && (enable_recombination || enable_scattering)) || ph_scratch || no_scratch_ok,
              "ph_scratch is required when phonons are updated by the generic kernel");
   QP_REQUIRE((t->diag_bin == nullptr) == (t->anti_bin == nullptr), "diag_bin and anti_bin come together");
-  if (t->diag_bin && t->nclass == 1 &&
+  if (t->diag_bin && t->nclass == 1 && !(t->flags & (QP_COLL_FORCE_GENERIC | QP_COLL_FORCE_WAVE)) &&
       qp::collision_fast_dispatch(t->ne, t->kr0, t->ks0, t->rho, t->diag_bin, t->anti_bin, flags, (long)ncell, state_in,
                                   state_out, phonon, dE, dt, enable_recombination, enable_scattering, update_phonons,
                                   (hipStream_t)stream))
     return qp::check_launch("qp_collision_step(fast)");
+  // NE <= 64: one wave per pixel (any class map; LDS atomics unless the host vouched for the bin-map structure)
+  if (!(t->flags & QP_COLL_FORCE_GENERIC)) {
+    qp::WaveCollView wv{t->ne, t->nw, t->nclass, t->kr0, t->ks0, t->rho, t->idx_diff, t->idx_sum, t->sign, t->cls};
+    if (qp::collision_wave_dispatch(wv, t->diag_bin != nullptr, flags, (long)ncell, state_in, state_out, phonon, dE, dt,
+                                    enable_recombination, enable_scattering, update_phonons, (hipStream_t)stream))
+      return qp::check_launch("qp_collision_step(wave)");
+  }
   qp::CollView v{t->ne, t->nw, t->nclass, t->kr0, t->ks0, t->rho, t->idx_diff, t->idx_sum, t->sign, t->cls};
   const unsigned blocks = (unsigned)((ncell + 255) / 256);
   hipLaunchKernelGGL(qp::collision_generic_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, flags,

@@ -376,7 +376,9 @@ class Engine:
         return float(self._red_vals[0].item())
 
     # -- collisions, generation, reductions -------------------------------------------------------------------
-    def make_collision_tables(self, kr0, ks0, rho, idx_diff, idx_sum, sign, cls_packed=None, allow_fast=True):
+    def make_collision_tables(self, kr0, ks0, rho, idx_diff, idx_sum, sign, cls_packed=None, allow_fast=True,
+                              kernel: str = "auto"):
+        """``kernel``: "auto" | "generic" | "wave" (force a specific collision kernel; tests and A/B timing)."""
         """Upload per-gap-class tables ([C,NE,NE], [C,NE]) and maps; returns an opaque handle."""
         torch = self.torch
         up = lambda a, dt: None if a is None else torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=self.device)  # noqa: E731
@@ -395,13 +397,19 @@ class Engine:
             h["cls"] = up(full, np.int32)
         h["nw"] = nw
         h["diag_bin"] = h["anti_bin"] = None
-        structure = None if (nclass > 1 or not allow_fast) else structured_bin_maps(idx_diff, idx_sum, sign)
+        structure = structured_bin_maps(idx_diff, idx_sum, sign)
         if structure is not None:
             h["diag_bin"], h["anti_bin"] = up(structure[0], np.int32), up(structure[1], np.int32)
-        h["fast"] = structure is not None and 2 <= ne <= 16
+        if not allow_fast and kernel == "auto":
+            kernel = "generic"
+        flag_bits = {"auto": 0, "generic": 1, "wave": 2}[kernel]
+        wave_ok = ne <= 64 and nw <= 192
+        h["kernel"] = ("generic" if (kernel == "generic" or not wave_ok) else
+                       "register" if (kernel == "auto" and structure is not None and nclass == 1 and 2 <= ne <= 16) else "wave")
+        h["fast"] = h["kernel"] != "generic"      # no accumulator planes needed
         h["struct"] = _hip.CollisionTables(ne, nw, nclass, _ptr(h["kr0"]), _ptr(h["ks0"]), _ptr(h["rho"]),
                                            _ptr(h["idx_diff"]), _ptr(h["idx_sum"]), _ptr(h["sign"]), _ptr(h["cls"]),
-                                           _ptr(h["diag_bin"]), _ptr(h["anti_bin"]))
+                                           _ptr(h["diag_bin"]), _ptr(h["anti_bin"]), flag_bits)
         return h
 
     def collide(self, tables, state, state_out, phonon, dE, dt, en_r, en_s, update_phonons):

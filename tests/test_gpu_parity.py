@@ -547,3 +547,67 @@ def test_energy_integral_and_weighted_sum_kernels():
     assert np.array_equal(got, np.sum(state, axis=0) * 0.37)      # same sequential order as np.sum(axis=0)
     got = eng.weighted_sum(d, w).cpu().numpy()[mask.reshape(-1)]
     assert rel_err(got, np.sum(state * w[:, None], axis=0)) < 1e-15
+
+
+@pytest.mark.parametrize("ne,fmax,nclass", [(6, 3.0, 1), (12, 3.0, 1), (24, 4.0, 1), (50, 10.0, 1), (64, 10.0, 1),
+                                            (18, 10.0, 1), (10, 3.0, 3), (50, 10.0, 2)])
+@pytest.mark.parametrize("en_r,en_s,upd", [(True, True, True), (True, False, True), (False, True, False)])
+def test_wave_collision_kernel_matches_generic_and_oracle(O, ne, fmax, nclass, en_r, en_s, upd):
+    """One-wave-per-pixel kernel (NE <= 64, gap classes, merged bins via LDS atomics) vs generic kernel and oracle."""
+    from qpsim_amd import tables as T
+    from qpsim_amd.engine import CompiledGeometry, Engine, link_flags, structured_bin_maps
+    rng = np.random.default_rng(ne * 11 + nclass)
+    mask = rng.random((7, 23)) > 0.2
+    z = np.zeros(mask.shape)
+    eng = Engine(CompiledGeometry(mask, 1.0, link_flags(mask), z, z, z, z))
+    n = int(mask.sum())
+    gaps = np.array([180.0, 171.0, 188.5])[:nclass]
+    E, dE = T.build_energy_grid(180.0, 1.0, fmax, ne)
+    om, idx_d, idx_s, sg = T.build_phonon_frequency_map(E)
+    rho = np.stack([T.dynes_density_of_states(E, g, 0.1) for g in gaps])
+    kr = np.stack([T.recombination_kernel_base(E, g, 500.0, 1.2) for g in gaps])
+    ks = np.stack([T.scattering_kernel_base(E, g, 400.0, 1.2) for g in gaps])
+    cls = rng.integers(0, nclass, size=n)
+    state = rng.random((ne, n)) * rho[cls].T * rng.choice([1e-5, 1e-2, 0.5, 0.95], size=n)[None, :]
+    ph = T.thermal_phonon_occupation(om, 0.3)[:, None] * (0.5 + rng.random((om.size, n)))
+    merged = structured_bin_maps(idx_d, idx_s, sg) is None
+    assert merged == (ne == 18)
+    outs = {}
+    for kern in ("wave", "generic"):
+        tab = eng.make_collision_tables(kr, ks, rho, idx_d, idx_s, sg, cls if nclass > 1 else None, kernel=kern)
+        assert tab["kernel"] == kern
+        s_in, p_dev = eng.upload_packed(state), eng.upload_packed(ph)
+        s_out = eng.empty(ne, eng.ncell)
+        eng.collide(tab, s_in, s_out, p_dev, dE, 0.37, en_r, en_s, upd)
+        outs[kern] = (eng.download_packed(s_out), eng.download_packed(p_dev), s_out.cpu().numpy(), p_dev.cpu().numpy())
+    assert rel_err(outs["wave"][0], outs["generic"][0]) < 1e-12 and rel_err(outs["wave"][1], outs["generic"][1]) < 1e-11
+    hole = ~mask.reshape(-1)
+    assert np.all(outs["wave"][2][:, hole] == 0.0) and np.all(outs["wave"][3][:, hole] == 0.0)
+    tables = {"rho": rho, "Kr0": kr if en_r else None, "Ks0": ks if en_s else None, "cls": cls, "idx_diff": idx_d,
+              "idx_sum": idx_s, "sign": sg, "dE": dE}
+    s_ref, p_ref = state.copy(), ph.copy()
+    O.collision_step(s_ref, p_ref, tables, 0.37, en_r=en_r, en_s=en_s, update_phonons=upd)
+    assert rel_err(outs["wave"][0], s_ref) < 2e-11 and rel_err(outs["wave"][1], p_ref) < 2e-11
+    if not upd:
+        assert np.array_equal(outs["wave"][1], ph)
+
+
+def test_collision_kernel_selection():
+    from qpsim_amd import tables as T
+    from qpsim_amd.engine import CompiledGeometry, Engine, link_flags
+    mask = np.ones((1, 8), dtype=bool)
+    z = np.zeros(mask.shape)
+    eng = Engine(CompiledGeometry(mask, 1.0, link_flags(mask), z, z, z, z))
+
+    def pick(ne, fmax, nclass=1):
+        E, _ = T.build_energy_grid(180.0, 1.0, fmax, ne)
+        om, idd, ids, sg = T.build_phonon_frequency_map(E)
+        rho = np.ones((nclass, ne))
+        k = np.zeros((nclass, ne, ne))
+        return eng.make_collision_tables(k, k, rho, idd, ids, sg, np.zeros(8, dtype=int) if nclass > 1 else None)["kernel"]
+
+    assert pick(12, 3.0) == "register" and pick(16, 10.0) == "register"
+    assert pick(17, 3.0) == "wave" and pick(50, 10.0) == "wave" and pick(64, 10.0) == "wave"
+    assert pick(18, 10.0) == "wave"            # merged bins: not eligible for the register kernel
+    assert pick(12, 3.0, nclass=2) == "wave"   # gap classes
+    assert pick(65, 10.0) == "generic"
