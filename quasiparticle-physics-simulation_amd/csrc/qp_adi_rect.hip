@@ -181,29 +181,33 @@ __device__ __forceinline__ TileCoord tile_coord(const RectDims& d) {
   return t;
 }
 
+// Row r of the tile starts at a wave-uniform address; the lane only adds a 32-bit offset, so the accesses use the
+// SGPR-base + VGPR-offset addressing mode (no 64-bit address arithmetic per row).
 __device__ __forceinline__ void load_cols(const double* __restrict__ base, const TileCoord& t, int nx, int lane,
                                           double (&v)[TS]) {
-  const double* p = base + (long)t.j0 * nx + t.i0 + lane;
+  const double* p = base + (long)t.j0 * nx + t.i0;
+  const unsigned l = (unsigned)lane;
   if (t.nr == TS && t.nc == TS) {      // interior tile (wave-uniform test): 64 unconditional row-segment loads
 #pragma unroll
-    for (int r = 0; r < TS; ++r) v[r] = p[(long)r * nx];
+    for (int r = 0; r < TS; ++r) v[r] = (p + (long)r * nx)[l];
   } else {
     const bool on = lane < t.nc;
 #pragma unroll
-    for (int r = 0; r < TS; ++r) v[r] = (on && r < t.nr) ? p[(long)r * nx] : 0.0;
+    for (int r = 0; r < TS; ++r) v[r] = (on && r < t.nr) ? (p + (long)r * nx)[l] : 0.0;
   }
 }
 
 __device__ __forceinline__ void store_cols(double* __restrict__ base, const TileCoord& t, int nx, int lane,
                                            const double (&v)[TS]) {
-  double* p = base + (long)t.j0 * nx + t.i0 + lane;
+  double* p = base + (long)t.j0 * nx + t.i0;
+  const unsigned l = (unsigned)lane;
   if (t.nr == TS && t.nc == TS) {
 #pragma unroll
-    for (int r = 0; r < TS; ++r) p[(long)r * nx] = v[r];
+    for (int r = 0; r < TS; ++r) (p + (long)r * nx)[l] = v[r];
   } else if (lane < t.nc) {
 #pragma unroll
     for (int r = 0; r < TS; ++r)
-      if (r < t.nr) p[(long)r * nx] = v[r];
+      if (r < t.nr) (p + (long)r * nx)[l] = v[r];
   }
 }
 

@@ -59,22 +59,46 @@ __device__ __forceinline__ void bin_add(double* arr, int bin, double v) {
 constexpr int PB = 8;        // pixels per wave
 constexpr int MAXBINS = 3;   // phonon bins per lane: NW <= 3*64 - 1 for NE <= 64
 
-template <bool ATOMIC>
-__global__ void __launch_bounds__(64) collision_wave_kernel(WaveCollView t, const uint8_t* __restrict__ flags, long ncell,
-                                                            const double* __restrict__ sin_, double* __restrict__ sout,
-                                                            double* __restrict__ ph, double dE, double dt, int en_r,
-                                                            int en_s, int upd_ph) {
+// STAGED (one gap class): the block's 4 waves first copy K^s_0, K^r_0, idx_diff, idx_sum and sign into LDS and then read
+// row j from there; otherwise the rows come from global memory (L1/L2) with the class offset of the pixel.
+// Waves of a block work on different pixel groups and only synchronise once (after staging); inside a wave LDS accesses
+// execute in order, so wave_barrier() (a code-motion barrier) is all that is needed between the phases of a pixel.
+constexpr int WAVES = 4;
+
+template <bool ATOMIC, bool STAGED>
+__global__ void __launch_bounds__(64 * WAVES) collision_wave_kernel(WaveCollView t, const uint8_t* __restrict__ flags,
+                                                                   long ncell, const double* __restrict__ sin_,
+                                                                   double* __restrict__ sout, double* __restrict__ ph,
+                                                                   double dE, double dt, int en_r, int en_s, int upd_ph) {
   extern __shared__ double lds[];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int NE = t.ne, NW = t.nw;
-  double* pP = lds;             // phonon occupations of the current pixel
-  double* A = lds + NW;         // sum of "a" terms (emission, recombination)
-  double* Bm = lds + 2 * NW;    // sum of the negative "b" terms (absorption, pair breaking): b = A - Bm
-  const long p0 = (long)blockIdx.x * PB;
-  const int npx = (int)min((long)PB, ncell - p0);
-  const bool on = lane < NE;
   const bool use_s = en_s && t.ks0, use_r = en_r && t.kr0;
   const bool do_ph = upd_ph && (use_s || use_r);
+  // LDS carve-up: [tables (STAGED)] [per-wave: pP, A, Bm]
+  double* l_ks = lds;
+  double* l_kr = l_ks + (STAGED ? NE * NE : 0);
+  int* l_idd = (int*)(l_kr + (STAGED ? NE * NE : 0));
+  int* l_ids = l_idd + (STAGED ? NE * NE : 0);
+  signed char* l_sg = (signed char*)(l_ids + (STAGED ? NE * NE : 0));
+  double* wave_base = (double*)(((uintptr_t)(l_sg + (STAGED ? NE * NE : 0)) + 15) & ~(uintptr_t)15);
+  double* pP = wave_base + (long)wave * 3 * NW;   // phonon occupations of the current pixel
+  double* A = pP + NW;                            // sum of "a" terms (emission, recombination)
+  double* Bm = A + NW;                            // sum of the negative "b" terms: b = A - Bm
+  if (STAGED) {
+    for (int q = threadIdx.x; q < NE * NE; q += 64 * WAVES) {
+      l_ks[q] = use_s ? t.ks0[q] : 0.0;
+      l_kr[q] = use_r ? t.kr0[q] : 0.0;
+      l_idd[q] = t.idx_diff[q];
+      l_ids[q] = t.idx_sum[q];
+      l_sg[q] = t.sign[q];
+    }
+    __syncthreads();
+  }
+  const long p0 = ((long)blockIdx.x * WAVES + wave) * PB;
+  if (p0 >= ncell) return;
+  const int npx = (int)min((long)PB, ncell - p0);
+  const bool on = lane < NE;
 
   double n[PB], pb[MAXBINS][PB];
 #pragma unroll
@@ -90,7 +114,7 @@ __global__ void __launch_bounds__(64) collision_wave_kernel(WaveCollView t, cons
   for (int k = 0; k < PB; ++k) {
     if (k >= npx) break;
     if (!(flags[p0 + k] & QP_FLAG_ACTIVE)) continue;      // wave-uniform: holes pass through unchanged
-    const int c = t.cls ? t.cls[p0 + k] : 0;
+    const int c = (!STAGED && t.cls) ? t.cls[p0 + k] : 0;
     const double rho_i = on ? t.rho[(long)c * NE + lane] : 0.0;
     const double* ks = use_s ? t.ks0 + (long)c * NE * NE : nullptr;
     const double* kr = use_r ? t.kr0 + (long)c * NE * NE : nullptr;
@@ -101,22 +125,23 @@ __global__ void __launch_bounds__(64) collision_wave_kernel(WaveCollView t, cons
       const int w = lane + 64 * s;
       if (w < NW) { pP[w] = pb[s][k]; A[w] = 0.0; Bm[w] = 0.0; }
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     double g_s = 0.0, l_s = 0.0, g_r = 0.0, l_r = 0.0;
     for (int j = 0; j < NE; ++j) {
       const double nj = bcast(ni, j), qj = bcast(qi, j);
+      const int row = on ? j * NE + lane : 0;
       if (use_s) {
-        const double K = on ? ks[j * NE + lane] : 0.0;
-        const int d = on ? t.idx_diff[j * NE + lane] : 0;
-        const int sg = on ? -(int)t.sign[j * NE + lane] : 0;     // sign(E_lane - E_j)
+        const double K = on ? (STAGED ? l_ks[row] : ks[row]) : 0.0;
+        const int d = STAGED ? l_idd[row] : t.idx_diff[row];
+        const int sg = on ? -(int)(STAGED ? l_sg[row] : t.sign[row]) : 0;     // sign(E_lane - E_j)
         const double P = pP[d];
         g_s = fma(K * (sg < 0 ? 1.0 + P : P), nj, g_s);          // K^s_eff[j][i] n_j
         l_s = fma(K * (sg > 0 ? 1.0 + P : P), qj, l_s);          // K^s_eff[i][j] q_j
         if (do_ph && sg != 0) bin_add<ATOMIC>(sg > 0 ? A : Bm, d, dE * (ni * K * qj));
       }
       if (use_r) {
-        const double K = on ? kr[j * NE + lane] : 0.0;
-        const int s = on ? t.idx_sum[j * NE + lane] : 0;
+        const double K = on ? (STAGED ? l_kr[row] : kr[row]) : 0.0;
+        const int s = STAGED ? l_ids[row] : t.idx_sum[row];
         const double P = pP[s];
         l_r = fma(K * (1.0 + P), nj, l_r);
         g_r = fma(K * P, qj, g_r);
@@ -127,7 +152,7 @@ __global__ void __launch_bounds__(64) collision_wave_kernel(WaveCollView t, cons
       }
     }
     n[k] = relax_update_w(ni, dE * qi * g_s + 2.0 * dE * qi * g_r, dE * l_s + 2.0 * dE * l_r, dt);
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     if (do_ph) {
 #pragma unroll
       for (int s = 0; s < MAXBINS; ++s) {
@@ -135,7 +160,7 @@ __global__ void __launch_bounds__(64) collision_wave_kernel(WaveCollView t, cons
         if (w < NW) pb[s][k] = affine_update_w(pb[s][k], A[w], A[w] - Bm[w], dt);
       }
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
   }
 
   if (on) {
@@ -161,14 +186,23 @@ bool collision_wave_dispatch(const WaveCollView& v, bool structured, const uint8
                              double* sout, double* ph, double dE, double dt, int en_r, int en_s, int upd,
                              hipStream_t stream) {
   if (v.ne > 64 || v.nw > 64 * MAXBINS) return false;
-  const unsigned blocks = (unsigned)((ncell + PB - 1) / PB);
-  const size_t shmem = (size_t)3 * v.nw * sizeof(double);
-  if (structured)
-    hipLaunchKernelGGL(collision_wave_kernel<false>, dim3(blocks), dim3(64), shmem, stream, v, flags, ncell, sin_, sout, ph,
-                       dE, dt, en_r, en_s, upd);
-  else
-    hipLaunchKernelGGL(collision_wave_kernel<true>, dim3(blocks), dim3(64), shmem, stream, v, flags, ncell, sin_, sout, ph,
-                       dE, dt, en_r, en_s, upd);
+  const unsigned blocks = (unsigned)((ncell + (long)PB * WAVES - 1) / ((long)PB * WAVES));
+  const size_t per_wave = (size_t)3 * v.nw * sizeof(double);
+  const size_t table_bytes = (size_t)v.ne * v.ne * (8 + 8 + 4 + 4 + 1) + 16;
+  const bool staged = v.nclass == 1 && table_bytes + WAVES * per_wave <= 150 * 1024;
+  const size_t shmem = (staged ? table_bytes : 16) + WAVES * per_wave;
+  // more than 64 KiB of dynamic LDS has to be allowed explicitly (gfx950 has 160 KiB per CU)
+#define QP_LAUNCH(AT, ST)                                                                                              \
+  do {                                                                                                                 \
+    if (shmem > 48 * 1024)                                                                                             \
+      (void)hipFuncSetAttribute((const void*)collision_wave_kernel<AT, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)shmem);                                                                           \
+    hipLaunchKernelGGL((collision_wave_kernel<AT, ST>), dim3(blocks), dim3(64 * WAVES), shmem, stream, v, flags, ncell, \
+                       sin_, sout, ph, dE, dt, en_r, en_s, upd);                                                       \
+  } while (0)
+  if (structured) { if (staged) QP_LAUNCH(false, true); else QP_LAUNCH(false, false); }
+  else { if (staged) QP_LAUNCH(true, true); else QP_LAUNCH(true, false); }
+#undef QP_LAUNCH
   return true;
 }
 
