@@ -11,6 +11,8 @@
 // lanes) serves the pair (lane, j).  Per-bin sums: for a fixed j the lanes of one instruction hit distinct bins when the
 // maps have the |i-j| / i+j structure (emission and absorption go to different arrays), so a plain read-modify-write by
 // the single wave is race-free and deterministic; otherwise (unstructured maps) LDS atomics are used.
+#include <algorithm>
+
 #include "qp_common.h"
 
 namespace qp {
@@ -50,132 +52,130 @@ __device__ __forceinline__ double bcast(double x, int srclane) {
   return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
-template <bool ATOMIC>
-__device__ __forceinline__ void bin_add(double* arr, int bin, double v) {
-  if (ATOMIC) atomicAdd(arr + bin, v);
-  else arr[bin] += v;
-}
-
-constexpr int PB = 8;        // pixels per wave
+constexpr int PB = 8;        // pixels per wave and group
 constexpr int MAXBINS = 3;   // phonon bins per lane: NW <= 3*64 - 1 for NE <= 64
-
-// STAGED (one gap class): the block's 4 waves first copy K^s_0, K^r_0, idx_diff, idx_sum and sign into LDS and then read
-// row j from there; otherwise the rows come from global memory (L1/L2) with the class offset of the pixel.
-// Waves of a block work on different pixel groups and only synchronise once (after staging); inside a wave LDS accesses
-// execute in order, so wave_barrier() (a code-motion barrier) is all that is needed between the phases of a pixel.
 constexpr int WAVES = 4;
 
+// STAGED (one gap class): the block's 4 waves first copy K^s_0, K^r_0, idx_diff, idx_sum and sign into LDS and then read
+// row j from there; otherwise the rows come from global memory (L1/L2) with the class offset of the pixel.  Blocks are
+// persistent (each wave strides over groups of 8 pixels), so the staging cost is paid once per block.
+// Waves only synchronise once (after staging); inside a wave LDS accesses execute in order, so wave_barrier() (a
+// code-motion barrier) is all that is needed between the phases of a pixel.
+// Every shared access is written as lds[integer index]: pointer selects or integer round-trips of the base make the
+// compiler fall back to flat (generic address space) accesses, which are several times slower than ds_* instructions.
 template <bool ATOMIC, bool STAGED>
 __global__ void __launch_bounds__(64 * WAVES) collision_wave_kernel(WaveCollView t, const uint8_t* __restrict__ flags,
                                                                    long ncell, const double* __restrict__ sin_,
                                                                    double* __restrict__ sout, double* __restrict__ ph,
                                                                    double dE, double dt, int en_r, int en_s, int upd_ph) {
   extern __shared__ double lds[];
+  int* ilds = (int*)lds;
+  signed char* blds = (signed char*)lds;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int NE = t.ne, NW = t.nw;
+  const int NE = t.ne, NW = t.nw, NN = NE * NE;
   const bool use_s = en_s && t.ks0, use_r = en_r && t.kr0;
   const bool do_ph = upd_ph && (use_s || use_r);
-  // LDS carve-up: [tables (STAGED)] [per-wave: pP, A, Bm]
-  double* l_ks = lds;
-  double* l_kr = l_ks + (STAGED ? NE * NE : 0);
-  int* l_idd = (int*)(l_kr + (STAGED ? NE * NE : 0));
-  int* l_ids = l_idd + (STAGED ? NE * NE : 0);
-  signed char* l_sg = (signed char*)(l_ids + (STAGED ? NE * NE : 0));
-  double* wave_base = (double*)(((uintptr_t)(l_sg + (STAGED ? NE * NE : 0)) + 15) & ~(uintptr_t)15);
-  double* pP = wave_base + (long)wave * 3 * NW;   // phonon occupations of the current pixel
-  double* A = pP + NW;                            // sum of "a" terms (emission, recombination)
-  double* Bm = A + NW;                            // sum of the negative "b" terms: b = A - Bm
+  // carve-up (STAGED): doubles [0, NN) K^s, [NN, 2NN) K^r; ints [4NN, 5NN) idx_diff, [5NN, 6NN) idx_sum; bytes [24NN, 25NN) sign
+  const int o_kr = NN, o_idd = 4 * NN, o_ids = 5 * NN, o_sg = 24 * NN;
+  const int o_wave = (STAGED ? (25 * NN + 7) / 8 : 0) + wave * 3 * NW;   // per-wave: pP | A | Bm
+  const int o_A = o_wave + NW, o_B = o_wave + 2 * NW;
   if (STAGED) {
-    for (int q = threadIdx.x; q < NE * NE; q += 64 * WAVES) {
-      l_ks[q] = use_s ? t.ks0[q] : 0.0;
-      l_kr[q] = use_r ? t.kr0[q] : 0.0;
-      l_idd[q] = t.idx_diff[q];
-      l_ids[q] = t.idx_sum[q];
-      l_sg[q] = t.sign[q];
+    for (int q = threadIdx.x; q < NN; q += 64 * WAVES) {
+      lds[q] = use_s ? t.ks0[q] : 0.0;
+      lds[o_kr + q] = use_r ? t.kr0[q] : 0.0;
+      ilds[o_idd + q] = t.idx_diff[q];
+      ilds[o_ids + q] = t.idx_sum[q];
+      blds[o_sg + q] = t.sign[q];
     }
     __syncthreads();
   }
-  const long p0 = ((long)blockIdx.x * WAVES + wave) * PB;
-  if (p0 >= ncell) return;
-  const int npx = (int)min((long)PB, ncell - p0);
   const bool on = lane < NE;
-
-  double n[PB], pb[MAXBINS][PB];
+  const long ngroups = (ncell + PB - 1) / PB;
+  for (long grp = (long)blockIdx.x * WAVES + wave; grp < ngroups; grp += (long)gridDim.x * WAVES) {
+    const long p0 = grp * PB;
+    const int npx = (int)min((long)PB, ncell - p0);
+    double n[PB], pb[MAXBINS][PB];
 #pragma unroll
-  for (int k = 0; k < PB; ++k) n[k] = (on && k < npx) ? sin_[(long)lane * ncell + p0 + k] : 0.0;
-#pragma unroll
-  for (int s = 0; s < MAXBINS; ++s) {
-    const int w = lane + 64 * s;
-#pragma unroll
-    for (int k = 0; k < PB; ++k) pb[s][k] = (w < NW && k < npx) ? ph[(long)w * ncell + p0 + k] : 0.0;
-  }
-
-#pragma unroll
-  for (int k = 0; k < PB; ++k) {
-    if (k >= npx) break;
-    if (!(flags[p0 + k] & QP_FLAG_ACTIVE)) continue;      // wave-uniform: holes pass through unchanged
-    const int c = (!STAGED && t.cls) ? t.cls[p0 + k] : 0;
-    const double rho_i = on ? t.rho[(long)c * NE + lane] : 0.0;
-    const double* ks = use_s ? t.ks0 + (long)c * NE * NE : nullptr;
-    const double* kr = use_r ? t.kr0 + (long)c * NE * NE : nullptr;
-    const double ni = n[k];
-    const double qi = rho_i * fmax(1.0 - ni / fmax(rho_i, 1e-30), 0.0);
+    for (int k = 0; k < PB; ++k) n[k] = (on && k < npx) ? sin_[(long)lane * ncell + p0 + k] : 0.0;
 #pragma unroll
     for (int s = 0; s < MAXBINS; ++s) {
       const int w = lane + 64 * s;
-      if (w < NW) { pP[w] = pb[s][k]; A[w] = 0.0; Bm[w] = 0.0; }
+#pragma unroll
+      for (int k = 0; k < PB; ++k) pb[s][k] = (w < NW && k < npx) ? ph[(long)w * ncell + p0 + k] : 0.0;
     }
-    __builtin_amdgcn_wave_barrier();
-    double g_s = 0.0, l_s = 0.0, g_r = 0.0, l_r = 0.0;
-    for (int j = 0; j < NE; ++j) {
-      const double nj = bcast(ni, j), qj = bcast(qi, j);
-      const int row = on ? j * NE + lane : 0;
-      if (use_s) {
-        const double K = on ? (STAGED ? l_ks[row] : ks[row]) : 0.0;
-        const int d = STAGED ? l_idd[row] : t.idx_diff[row];
-        const int sg = on ? -(int)(STAGED ? l_sg[row] : t.sign[row]) : 0;     // sign(E_lane - E_j)
-        const double P = pP[d];
-        g_s = fma(K * (sg < 0 ? 1.0 + P : P), nj, g_s);          // K^s_eff[j][i] n_j
-        l_s = fma(K * (sg > 0 ? 1.0 + P : P), qj, l_s);          // K^s_eff[i][j] q_j
-        if (do_ph && sg != 0) bin_add<ATOMIC>(sg > 0 ? A : Bm, d, dE * (ni * K * qj));
+
+#pragma unroll
+    for (int k = 0; k < PB; ++k) {
+      if (k >= npx) break;
+      if (!(flags[p0 + k] & QP_FLAG_ACTIVE)) continue;      // wave-uniform: holes pass through unchanged
+      const int c = (!STAGED && t.cls) ? t.cls[p0 + k] : 0;
+      const double rho_i = on ? t.rho[(long)c * NE + lane] : 0.0;
+      const double* ks = use_s ? t.ks0 + (long)c * NN : nullptr;
+      const double* kr = use_r ? t.kr0 + (long)c * NN : nullptr;
+      const double ni = n[k];
+      const double qi = rho_i * fmax(1.0 - ni / fmax(rho_i, 1e-30), 0.0);
+#pragma unroll
+      for (int s = 0; s < MAXBINS; ++s) {
+        const int w = lane + 64 * s;
+        if (w < NW) { lds[o_wave + w] = pb[s][k]; lds[o_A + w] = 0.0; lds[o_B + w] = 0.0; }
       }
-      if (use_r) {
-        const double K = on ? (STAGED ? l_kr[row] : kr[row]) : 0.0;
-        const int s = STAGED ? l_ids[row] : t.idx_sum[row];
-        const double P = pP[s];
-        l_r = fma(K * (1.0 + P), nj, l_r);
-        g_r = fma(K * P, qj, g_r);
-        if (do_ph && on) {
-          bin_add<ATOMIC>(A, s, dE * (ni * K * nj));
-          bin_add<ATOMIC>(Bm, s, dE * (qi * K * qj));
+      __builtin_amdgcn_wave_barrier();
+      double g_s = 0.0, l_s = 0.0, g_r = 0.0, l_r = 0.0;
+      for (int j = 0; j < NE; ++j) {
+        const double nj = bcast(ni, j), qj = bcast(qi, j);
+        const int row = on ? j * NE + lane : 0;
+        if (use_s) {
+          const double K = on ? (STAGED ? lds[row] : ks[row]) : 0.0;
+          const int d = STAGED ? ilds[o_idd + row] : t.idx_diff[row];
+          const int sg = on ? -(int)(STAGED ? blds[o_sg + row] : t.sign[row]) : 0;     // sign(E_lane - E_j)
+          const double P = lds[o_wave + d];
+          g_s = fma(K * (sg < 0 ? 1.0 + P : P), nj, g_s);          // K^s_eff[j][i] n_j
+          l_s = fma(K * (sg > 0 ? 1.0 + P : P), qj, l_s);          // K^s_eff[i][j] q_j
+          if (do_ph && sg != 0) {
+            const int slot = (sg > 0 ? o_A : o_B) + d;
+            const double v = dE * (ni * K * qj);
+            if (ATOMIC) atomicAdd(&lds[slot], v); else lds[slot] += v;
+          }
+        }
+        if (use_r) {
+          const double K = on ? (STAGED ? lds[o_kr + row] : kr[row]) : 0.0;
+          const int s = STAGED ? ilds[o_ids + row] : t.idx_sum[row];
+          const double P = lds[o_wave + s];
+          l_r = fma(K * (1.0 + P), nj, l_r);
+          g_r = fma(K * P, qj, g_r);
+          if (do_ph && on) {
+            const double va = dE * (ni * K * nj), vb = dE * (qi * K * qj);
+            if (ATOMIC) { atomicAdd(&lds[o_A + s], va); atomicAdd(&lds[o_B + s], vb); }
+            else { lds[o_A + s] += va; lds[o_B + s] += vb; }
+          }
         }
       }
+      n[k] = relax_update_w(ni, dE * qi * g_s + 2.0 * dE * qi * g_r, dE * l_s + 2.0 * dE * l_r, dt);
+      __builtin_amdgcn_wave_barrier();
+      if (do_ph) {
+#pragma unroll
+        for (int s = 0; s < MAXBINS; ++s) {
+          const int w = lane + 64 * s;
+          if (w < NW) pb[s][k] = affine_update_w(pb[s][k], lds[o_A + w], lds[o_A + w] - lds[o_B + w], dt);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
     }
-    n[k] = relax_update_w(ni, dE * qi * g_s + 2.0 * dE * qi * g_r, dE * l_s + 2.0 * dE * l_r, dt);
-    __builtin_amdgcn_wave_barrier();
+
+    if (on) {
+#pragma unroll
+      for (int k = 0; k < PB; ++k)
+        if (k < npx) sout[(long)lane * ncell + p0 + k] = n[k];
+    }
     if (do_ph) {
 #pragma unroll
       for (int s = 0; s < MAXBINS; ++s) {
         const int w = lane + 64 * s;
-        if (w < NW) pb[s][k] = affine_update_w(pb[s][k], A[w], A[w] - Bm[w], dt);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-
-  if (on) {
+        if (w < NW) {
 #pragma unroll
-    for (int k = 0; k < PB; ++k)
-      if (k < npx) sout[(long)lane * ncell + p0 + k] = n[k];
-  }
-  if (do_ph) {
-#pragma unroll
-    for (int s = 0; s < MAXBINS; ++s) {
-      const int w = lane + 64 * s;
-      if (w < NW) {
-#pragma unroll
-        for (int k = 0; k < PB; ++k)
-          if (k < npx) ph[(long)w * ncell + p0 + k] = pb[s][k];
+          for (int k = 0; k < PB; ++k)
+            if (k < npx) ph[(long)w * ncell + p0 + k] = pb[s][k];
+        }
       }
     }
   }
@@ -186,11 +186,14 @@ bool collision_wave_dispatch(const WaveCollView& v, bool structured, const uint8
                              double* sout, double* ph, double dE, double dt, int en_r, int en_s, int upd,
                              hipStream_t stream) {
   if (v.ne > 64 || v.nw > 64 * MAXBINS) return false;
-  const unsigned blocks = (unsigned)((ncell + (long)PB * WAVES - 1) / ((long)PB * WAVES));
+  const long need = (ncell + (long)PB * WAVES - 1) / ((long)PB * WAVES);
   const size_t per_wave = (size_t)3 * v.nw * sizeof(double);
-  const size_t table_bytes = (size_t)v.ne * v.ne * (8 + 8 + 4 + 4 + 1) + 16;
+  const size_t table_bytes = (((size_t)25 * v.ne * v.ne + 7) / 8) * 8;
   const bool staged = v.nclass == 1 && table_bytes + WAVES * per_wave <= 150 * 1024;
-  const size_t shmem = (staged ? table_bytes : 16) + WAVES * per_wave;
+  const size_t shmem = (staged ? table_bytes : 0) + WAVES * per_wave;
+  // persistent blocks: enough to fill 256 CUs at the LDS-limited residency, never more than the work
+  const long resident = 256L * std::max<long>(1, (long)(160 * 1024 / std::max<size_t>(shmem, 1)));
+  const unsigned blocks = (unsigned)std::min<long>(need, std::min<long>(resident, 256L * 8));
   // more than 64 KiB of dynamic LDS has to be allowed explicitly (gfx950 has 160 KiB per CU)
 #define QP_LAUNCH(AT, ST)                                                                                              \
   do {                                                                                                                 \
