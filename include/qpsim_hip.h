@@ -106,9 +106,9 @@ typedef struct qp_collision_tables {
   const int8_t* sign;      /* [ne][ne] sign(Ei-Ej) */
   const int32_t* cls;      /* [ncell] gap class per cell, or NULL when nclass == 1 */
   /* Optional structure hint (both or neither).  On the reference's uniform energy grid idx_diff[i][j] = diag_bin[|i-j|]
-   * and idx_sum[i][j] = anti_bin[i+j]; when the host has verified that AND that no phonon bin is shared between a
-   * diagonal and an anti-diagonal, passing the two arrays selects the register-resident kernel (nclass == 1, ne <= 16;
-   * ph_scratch unused).  NULL selects the generic table-driven kernel. */
+   * and idx_sum[i][j] = anti_bin[i+j], sign[i][j] = sign(i-j); pass the two arrays when the host has verified that.
+   * If a phonon bin is shared between a diagonal and an anti-diagonal (merged bins) also set QP_COLL_SHARED_BINS:
+   * the register-resident kernel (nclass == 1, ne <= 16) needs unshared bins, the one-wave-per-pixel kernel does not. */
   const int32_t* diag_bin; /* [ne] or NULL */
   const int32_t* anti_bin; /* [2*ne-1] or NULL */
   /* Kernel selection.  Default (0): register-resident kernel when (diag_bin, nclass == 1, ne <= 16); otherwise, for
@@ -118,6 +118,7 @@ typedef struct qp_collision_tables {
 } qp_collision_tables;
 #define QP_COLL_FORCE_GENERIC 1u
 #define QP_COLL_FORCE_WAVE 2u
+#define QP_COLL_SHARED_BINS 4u
 
 /*
  * One local coupled quasiparticle-phonon collision update of every interior cell

@@ -139,6 +139,8 @@ struct WaveCollView {
   const int32_t* idx_sum;
   const int8_t* sign;
   const int32_t* cls;
+  const int32_t* diag_bin;
+  const int32_t* anti_bin;
 };
 bool collision_wave_dispatch(const WaveCollView& v, bool structured, const uint8_t* flags, long ncell, const double* sin_,
                              double* sout, double* ph, double dE, double dt, int en_r, int en_s, int upd,
@@ -161,14 +163,15 @@ extern "C" int qp_collision_step(const qp_collision_tables* t, const uint8_t* fl
   QP_REQUIRE(!(update_phonons && (enable_recombination || enable_scattering)) || ph_scratch || no_scratch_ok,
              "ph_scratch is required when phonons are updated by the generic kernel");
   QP_REQUIRE((t->diag_bin == nullptr) == (t->anti_bin == nullptr), "diag_bin and anti_bin come together");
-  if (t->diag_bin && t->nclass == 1 && !(t->flags & (QP_COLL_FORCE_GENERIC | QP_COLL_FORCE_WAVE)) &&
+  if (t->diag_bin && t->nclass == 1 && !(t->flags & (QP_COLL_FORCE_GENERIC | QP_COLL_FORCE_WAVE | QP_COLL_SHARED_BINS)) &&
       qp::collision_fast_dispatch(t->ne, t->kr0, t->ks0, t->rho, t->diag_bin, t->anti_bin, flags, (long)ncell, state_in,
                                   state_out, phonon, dE, dt, enable_recombination, enable_scattering, update_phonons,
                                   (hipStream_t)stream))
     return qp::check_launch("qp_collision_step(fast)");
   // NE <= 64: one wave per pixel (any class map; LDS atomics unless the host vouched for the bin-map structure)
   if (!(t->flags & QP_COLL_FORCE_GENERIC)) {
-    qp::WaveCollView wv{t->ne, t->nw, t->nclass, t->kr0, t->ks0, t->rho, t->idx_diff, t->idx_sum, t->sign, t->cls};
+    qp::WaveCollView wv{t->ne, t->nw, t->nclass, t->kr0, t->ks0, t->rho, t->idx_diff, t->idx_sum, t->sign, t->cls,
+                        t->diag_bin, t->anti_bin};
     if (qp::collision_wave_dispatch(wv, t->diag_bin != nullptr, flags, (long)ncell, state_in, state_out, phonon, dE, dt,
                                     enable_recombination, enable_scattering, update_phonons, (hipStream_t)stream))
       return qp::check_launch("qp_collision_step(wave)");

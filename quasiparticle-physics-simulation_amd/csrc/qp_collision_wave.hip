@@ -28,6 +28,8 @@ struct WaveCollView {
   const int32_t* idx_sum;
   const int8_t* sign;
   const int32_t* cls;
+  const int32_t* diag_bin;   // [ne]     bin of |Ei-Ej| for |i-j| = k, or NULL (unstructured maps)
+  const int32_t* anti_bin;   // [2ne-1]  bin of Ei+Ej for i+j = m
 };
 
 __device__ __forceinline__ double relax_update_w(double n, double gain, double loss, double dt) {
@@ -63,7 +65,20 @@ constexpr int WAVES = 4;
 // code-motion barrier) is all that is needed between the phases of a pixel.
 // Every shared access is written as lds[integer index]: pointer selects or integer round-trips of the base make the
 // compiler fall back to flat (generic address space) accesses, which are several times slower than ds_* instructions.
-template <bool ATOMIC, bool STAGED>
+__device__ __forceinline__ double gather(double x, int srclane) {   // value of x on lane (srclane & 63)
+  const unsigned long long u = __double_as_longlong(x);
+  const int a = (srclane & 63) << 2;
+  const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(a, (int)(unsigned)u);
+  const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(a, (int)(unsigned)(u >> 32));
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+// STRUCT: the bin maps are idx_diff[i][j] = D[|i-j|], idx_sum[i][j] = S[i+j] (bins may be shared between a diagonal and
+// an anti-diagonal).  Then nothing in the j-loop has to touch LDS memory: lane l keeps the occupation of bins D[l], S[l],
+// S[l+64] and the running sums of diagonal l and anti-diagonals l, l+64; the occupation a pair needs and the pair's
+// contribution to those sums travel between lanes with ds_bpermute (a crossbar gather, no dependent read-modify-write).
+// The generic variant (ATOMIC or plain RMW on per-bin LDS slots) serves unstructured maps.
+template <bool ATOMIC, bool STAGED, bool STRUCT>
 __global__ void __launch_bounds__(64 * WAVES) collision_wave_kernel(WaveCollView t, const uint8_t* __restrict__ flags,
                                                                    long ncell, const double* __restrict__ sin_,
                                                                    double* __restrict__ sout, double* __restrict__ ph,
@@ -90,6 +105,12 @@ __global__ void __launch_bounds__(64 * WAVES) collision_wave_kernel(WaveCollView
     __syncthreads();
   }
   const bool on = lane < NE;
+  int binD = 0, binS0 = 0, binS1 = 0;
+  if (STRUCT) {
+    binD = on ? t.diag_bin[lane] : 0;
+    binS0 = lane < 2 * NE - 1 ? t.anti_bin[lane] : 0;
+    binS1 = lane + 64 < 2 * NE - 1 ? t.anti_bin[lane + 64] : 0;
+  }
   const long ngroups = (ncell + PB - 1) / PB;
   for (long grp = (long)blockIdx.x * WAVES + wave; grp < ngroups; grp += (long)gridDim.x * WAVES) {
     const long p0 = grp * PB;
@@ -121,6 +142,50 @@ __global__ void __launch_bounds__(64 * WAVES) collision_wave_kernel(WaveCollView
       }
       __builtin_amdgcn_wave_barrier();
       double g_s = 0.0, l_s = 0.0, g_r = 0.0, l_r = 0.0;
+      if (STRUCT) {
+        const double Pd = lds[o_wave + binD], Ps0 = lds[o_wave + binS0], Ps1 = lds[o_wave + binS1];
+        double em = 0.0, ab = 0.0, rec0 = 0.0, rec1 = 0.0, pb0 = 0.0, pb1 = 0.0;
+        for (int j = 0; j < NE; ++j) {
+          const double nj = bcast(ni, j), qj = bcast(qi, j);
+          const int row = on ? j * NE + lane : 0;
+          const int dlt = lane - j;
+          if (use_s) {
+            const double K = on ? (STAGED ? lds[row] : ks[row]) : 0.0;
+            const double P = gather(Pd, dlt < 0 ? -dlt : dlt);
+            g_s = fma(K * (dlt < 0 ? 1.0 + P : P), nj, g_s);
+            l_s = fma(K * (dlt > 0 ? 1.0 + P : P), qj, l_s);
+            if (do_ph) {
+              const double v = dE * (ni * K * qj);                 // pair (lane, j); zero on the diagonal (K = 0)
+              const double ve = gather(v, lane + j);               // from lane i = l + j > j: emission into diagonal l
+              const double va = gather(v, j - lane);               // from lane i = j - l < j: absorption
+              if (lane >= 1 && lane + j < NE) em += ve;
+              if (lane >= 1 && j - lane >= 0) ab += va;
+            }
+          }
+          if (use_r) {
+            const double K = on ? (STAGED ? lds[o_kr + row] : kr[row]) : 0.0;
+            const int m = lane + j;
+            const double Pa = gather(Ps0, m), Pb = gather(Ps1, m);
+            const double P = m < 64 ? Pa : Pb;
+            l_r = fma(K * (1.0 + P), nj, l_r);
+            g_r = fma(K * P, qj, g_r);
+            if (do_ph) {
+              const double vr = dE * (ni * K * nj), vp = dE * (qi * K * qj);
+              const double r0 = gather(vr, dlt), p0v = gather(vp, dlt);            // anti-diagonal m = l: source lane l - j
+              const double r1 = gather(vr, dlt + 64), p1v = gather(vp, dlt + 64);  // m = l + 64: source lane l + 64 - j
+              if (dlt >= 0 && dlt < NE) { rec0 += r0; pb0 += p0v; }
+              if (dlt + 64 >= 0 && dlt + 64 < NE) { rec1 += r1; pb1 += p1v; }
+            }
+          }
+        }
+        if (do_ph) {   // per-bin sums: diagonals first, then the anti-diagonals on top (bins may be shared)
+          if (lane >= 1 && on) { lds[o_A + binD] = em; lds[o_B + binD] = ab; }
+          __builtin_amdgcn_wave_barrier();
+          if (lane < 2 * NE - 1) { lds[o_A + binS0] += rec0; lds[o_B + binS0] += pb0; }
+          __builtin_amdgcn_wave_barrier();
+          if (lane + 64 < 2 * NE - 1) { lds[o_A + binS1] += rec1; lds[o_B + binS1] += pb1; }
+        }
+      } else {
       for (int j = 0; j < NE; ++j) {
         const double nj = bcast(ni, j), qj = bcast(qi, j);
         const int row = on ? j * NE + lane : 0;
@@ -149,6 +214,7 @@ __global__ void __launch_bounds__(64 * WAVES) collision_wave_kernel(WaveCollView
             else { lds[o_A + s] += va; lds[o_B + s] += vb; }
           }
         }
+      }
       }
       n[k] = relax_update_w(ni, dE * qi * g_s + 2.0 * dE * qi * g_r, dE * l_s + 2.0 * dE * l_r, dt);
       __builtin_amdgcn_wave_barrier();
@@ -195,16 +261,16 @@ bool collision_wave_dispatch(const WaveCollView& v, bool structured, const uint8
   const long resident = 256L * std::max<long>(1, (long)(160 * 1024 / std::max<size_t>(shmem, 1)));
   const unsigned blocks = (unsigned)std::min<long>(need, std::min<long>(resident, 256L * 8));
   // more than 64 KiB of dynamic LDS has to be allowed explicitly (gfx950 has 160 KiB per CU)
-#define QP_LAUNCH(AT, ST)                                                                                              \
+#define QP_LAUNCH(AT, ST, SR)                                                                                          \
   do {                                                                                                                 \
     if (shmem > 48 * 1024)                                                                                             \
-      (void)hipFuncSetAttribute((const void*)collision_wave_kernel<AT, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)shmem);                                                                           \
-    hipLaunchKernelGGL((collision_wave_kernel<AT, ST>), dim3(blocks), dim3(64 * WAVES), shmem, stream, v, flags, ncell, \
-                       sin_, sout, ph, dE, dt, en_r, en_s, upd);                                                       \
+      (void)hipFuncSetAttribute((const void*)collision_wave_kernel<AT, ST, SR>,                                        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                               \
+    hipLaunchKernelGGL((collision_wave_kernel<AT, ST, SR>), dim3(blocks), dim3(64 * WAVES), shmem, stream, v, flags,   \
+                       ncell, sin_, sout, ph, dE, dt, en_r, en_s, upd);                                                \
   } while (0)
-  if (structured) { if (staged) QP_LAUNCH(false, true); else QP_LAUNCH(false, false); }
-  else { if (staged) QP_LAUNCH(true, true); else QP_LAUNCH(true, false); }
+  if (structured) { if (staged) QP_LAUNCH(false, true, true); else QP_LAUNCH(false, false, true); }
+  else { if (staged) QP_LAUNCH(true, true, false); else QP_LAUNCH(true, false, false); }
 #undef QP_LAUNCH
   return true;
 }

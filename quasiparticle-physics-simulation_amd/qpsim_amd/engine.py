@@ -173,10 +173,10 @@ def rect_side_terms(geom: CompiledGeometry):
     return [xs[0], xs[1], ys[0], ys[1]], [xs[2], xs[3], ys[2], ys[3]]
 
 
-def structured_bin_maps(idx_diff, idx_sum, sign):
-    """(diag_bin[NE], anti_bin[2NE-1]) if idx_diff[i][j] depends only on |i-j|, idx_sum[i][j] only on i+j, sign is
-    sign(i-j), the tables are symmetric in that sense and no phonon bin is fed by both a diagonal (k >= 1) and an
-    anti-diagonal; None otherwise (merged bins, e.g. when 2 E_min / dE is an integer)."""
+def structured_bin_maps(idx_diff, idx_sum, sign, allow_shared: bool = False):
+    """(diag_bin[NE], anti_bin[2NE-1]) if idx_diff[i][j] depends only on |i-j|, idx_sum[i][j] only on i+j and sign is
+    sign(i-j); None otherwise.  Unless ``allow_shared``, None is also returned when a phonon bin is fed by both a
+    diagonal (k >= 1) and an anti-diagonal (merged bins, e.g. when 2 E_min / dE is an integer)."""
     idx_diff, idx_sum, sign = np.asarray(idx_diff), np.asarray(idx_sum), np.asarray(sign)
     ne = idx_diff.shape[0]
     if ne < 2:
@@ -187,8 +187,10 @@ def structured_bin_maps(idx_diff, idx_sum, sign):
     if not (np.array_equal(idx_diff, diag[np.abs(i - j)]) and np.array_equal(idx_sum, anti[i + j])
             and np.array_equal(sign, np.sign(i - j))):
         return None
+    if np.unique(diag[1:]).size != ne - 1 or np.unique(anti).size != anti.size:
+        return None
     used = np.concatenate([diag[1:], anti])
-    if np.unique(used).size != used.size:
+    if not allow_shared and np.unique(used).size != used.size:
         return None
     return diag.astype(np.int32), anti.astype(np.int32)
 
@@ -378,7 +380,7 @@ class Engine:
     # -- collisions, generation, reductions -------------------------------------------------------------------
     def make_collision_tables(self, kr0, ks0, rho, idx_diff, idx_sum, sign, cls_packed=None, allow_fast=True,
                               kernel: str = "auto"):
-        """``kernel``: "auto" | "generic" | "wave" (force a specific collision kernel; tests and A/B timing)."""
+        """``kernel``: "auto" | "generic" | "wave" | "wave_unstructured" (force a collision kernel; tests, A/B timing)."""
         """Upload per-gap-class tables ([C,NE,NE], [C,NE]) and maps; returns an opaque handle."""
         torch = self.torch
         up = lambda a, dt: None if a is None else torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=self.device)  # noqa: E731
@@ -397,15 +399,19 @@ class Engine:
             h["cls"] = up(full, np.int32)
         h["nw"] = nw
         h["diag_bin"] = h["anti_bin"] = None
-        structure = structured_bin_maps(idx_diff, idx_sum, sign)
-        if structure is not None:
+        structure = structured_bin_maps(idx_diff, idx_sum, sign, allow_shared=True)
+        shared = structure is not None and structured_bin_maps(idx_diff, idx_sum, sign) is None
+        if structure is not None and kernel != "wave_unstructured":
             h["diag_bin"], h["anti_bin"] = up(structure[0], np.int32), up(structure[1], np.int32)
         if not allow_fast and kernel == "auto":
             kernel = "generic"
-        flag_bits = {"auto": 0, "generic": 1, "wave": 2}[kernel]
+        flag_bits = {"auto": 0, "generic": 1, "wave": 2, "wave_unstructured": 2}[kernel] | (4 if shared else 0)
+        if kernel == "wave_unstructured":
+            kernel = "wave"
         wave_ok = ne <= 64 and nw <= 192
         h["kernel"] = ("generic" if (kernel == "generic" or not wave_ok) else
-                       "register" if (kernel == "auto" and structure is not None and nclass == 1 and 2 <= ne <= 16) else "wave")
+                       "register" if (kernel == "auto" and structure is not None and not shared and nclass == 1
+                                      and 2 <= ne <= 16) else "wave")
         h["fast"] = h["kernel"] != "generic"      # no accumulator planes needed
         h["struct"] = _hip.CollisionTables(ne, nw, nclass, _ptr(h["kr0"]), _ptr(h["ks0"]), _ptr(h["rho"]),
                                            _ptr(h["idx_diff"]), _ptr(h["idx_sum"]), _ptr(h["sign"]), _ptr(h["cls"]),

@@ -575,14 +575,16 @@ def test_wave_collision_kernel_matches_generic_and_oracle(O, ne, fmax, nclass, e
     merged = structured_bin_maps(idx_d, idx_s, sg) is None
     assert merged == (abs(ratio - round(ratio)) < 1e-9 and ratio <= ne - 2)
     outs = {}
-    for kern in ("wave", "generic"):
+    for kern in ("wave", "wave_unstructured", "generic"):
         tab = eng.make_collision_tables(kr, ks, rho, idx_d, idx_s, sg, cls if nclass > 1 else None, kernel=kern)
-        assert tab["kernel"] == kern
+        assert tab["kernel"] == kern.split("_")[0]
         s_in, p_dev = eng.upload_packed(state), eng.upload_packed(ph)
         s_out = eng.empty(ne, eng.ncell)
         eng.collide(tab, s_in, s_out, p_dev, dE, 0.37, en_r, en_s, upd)
         outs[kern] = (eng.download_packed(s_out), eng.download_packed(p_dev), s_out.cpu().numpy(), p_dev.cpu().numpy())
     assert rel_err(outs["wave"][0], outs["generic"][0]) < 1e-12 and rel_err(outs["wave"][1], outs["generic"][1]) < 1e-11
+    assert rel_err(outs["wave_unstructured"][0], outs["generic"][0]) < 1e-12
+    assert rel_err(outs["wave_unstructured"][1], outs["generic"][1]) < 1e-11
     hole = ~mask.reshape(-1)
     assert np.all(outs["wave"][2][:, hole] == 0.0) and np.all(outs["wave"][3][:, hole] == 0.0)
     tables = {"rho": rho, "Kr0": kr if en_r else None, "Ks0": ks if en_s else None, "cls": cls, "idx_diff": idx_d,
