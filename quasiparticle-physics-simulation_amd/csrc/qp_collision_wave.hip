@@ -57,6 +57,7 @@ __device__ __forceinline__ double bcast(double x, int srclane) {
 constexpr int PB = 8;        // pixels per wave and group
 constexpr int MAXBINS = 3;   // phonon bins per lane: NW <= 3*64 - 1 for NE <= 64
 constexpr int WAVES = 4;
+constexpr int PG = 4;        // pixels advanced together through the j-loop (structured variant)
 
 // STAGED (one gap class): the block's 4 waves first copy K^s_0, K^r_0, idx_diff, idx_sum and sign into LDS and then read
 // row j from there; otherwise the rows come from global memory (L1/L2) with the class offset of the pixel.  Blocks are
@@ -125,6 +126,113 @@ __global__ void __launch_bounds__(64 * WAVES) collision_wave_kernel(WaveCollView
       for (int k = 0; k < PB; ++k) pb[s][k] = (w < NW && k < npx) ? ph[(long)w * ncell + p0 + k] : 0.0;
     }
 
+    if (STRUCT) {
+      // PG pixels advance through the j-loop together: PG independent gather/accumulate chains per LDS wait, and (one
+      // gap class) one table row read for all of them.
+#pragma unroll
+      for (int k0 = 0; k0 < PB; k0 += PG) {
+        if (k0 >= npx) break;
+        bool act[PG];
+        double ni[PG], qi[PG], Pd[PG], Ps0[PG], Ps1[PG];
+        const double* ksq[PG];
+        const double* krq[PG];
+#pragma unroll
+        for (int q = 0; q < PG; ++q) {
+          const int k = k0 + q;
+          act[q] = k < npx && (flags[p0 + min(k, npx - 1)] & QP_FLAG_ACTIVE);
+          const int c = (!STAGED && t.cls && k < npx) ? t.cls[p0 + k] : 0;
+          const double rho_i = on ? t.rho[(long)c * NE + lane] : 0.0;
+          ksq[q] = use_s ? t.ks0 + (long)c * NN : nullptr;
+          krq[q] = use_r ? t.kr0 + (long)c * NN : nullptr;
+          ni[q] = n[k];
+          qi[q] = rho_i * fmax(1.0 - ni[q] / fmax(rho_i, 1e-30), 0.0);
+#pragma unroll
+          for (int s = 0; s < MAXBINS; ++s) {
+            const int w = lane + 64 * s;
+            if (w < NW) lds[o_wave + w] = pb[s][k];
+          }
+          __builtin_amdgcn_wave_barrier();
+          Pd[q] = lds[o_wave + binD];
+          Ps0[q] = lds[o_wave + binS0];
+          Ps1[q] = lds[o_wave + binS1];
+          __builtin_amdgcn_wave_barrier();
+        }
+        double g_s[PG], l_s[PG], g_r[PG], l_r[PG], em[PG], ab[PG], rec0[PG], rec1[PG], pb0[PG], pb1[PG];
+#pragma unroll
+        for (int q = 0; q < PG; ++q)
+          g_s[q] = l_s[q] = g_r[q] = l_r[q] = em[q] = ab[q] = rec0[q] = rec1[q] = pb0[q] = pb1[q] = 0.0;
+        for (int j = 0; j < NE; ++j) {
+          const int row = on ? j * NE + lane : 0;
+          const int dlt = lane - j, m = lane + j;
+          const bool em_ok = lane >= 1 && m < NE, ab_ok = lane >= 1 && dlt <= 0;
+          const bool r0_ok = dlt >= 0 && dlt < NE, r1_ok = dlt + 64 < NE;
+          double Ks_shared = 0.0, Kr_shared = 0.0;
+          if (STAGED) {
+            Ks_shared = (on && use_s) ? lds[row] : 0.0;
+            Kr_shared = (on && use_r) ? lds[o_kr + row] : 0.0;
+          }
+#pragma unroll
+          for (int q = 0; q < PG; ++q) {
+            const double nj = bcast(ni[q], j), qj = bcast(qi[q], j);
+            if (use_s) {
+              const double K = STAGED ? Ks_shared : (on ? ksq[q][row] : 0.0);
+              const double P = gather(Pd[q], dlt < 0 ? -dlt : dlt);
+              g_s[q] = fma(K * (dlt < 0 ? 1.0 + P : P), nj, g_s[q]);
+              l_s[q] = fma(K * (dlt > 0 ? 1.0 + P : P), qj, l_s[q]);
+              if (do_ph) {
+                const double v = dE * (ni[q] * K * qj);            // pair (lane, j); zero on the diagonal (K = 0)
+                const double ve = gather(v, m);                     // from lane l + j > j: emission into diagonal l
+                const double va = gather(v, -dlt);                  // from lane j - l < j: absorption
+                em[q] += em_ok ? ve : 0.0;
+                ab[q] += ab_ok ? va : 0.0;
+              }
+            }
+            if (use_r) {
+              const double K = STAGED ? Kr_shared : (on ? krq[q][row] : 0.0);
+              const double Pa = gather(Ps0[q], m), Pb = gather(Ps1[q], m);
+              const double P = m < 64 ? Pa : Pb;
+              l_r[q] = fma(K * (1.0 + P), nj, l_r[q]);
+              g_r[q] = fma(K * P, qj, g_r[q]);
+              if (do_ph) {
+                const double vr = dE * (ni[q] * K * nj), vp = dE * (qi[q] * K * qj);
+                const double r0 = gather(vr, dlt), p0v = gather(vp, dlt);            // anti-diagonal l: source lane l - j
+                const double r1 = gather(vr, dlt + 64), p1v = gather(vp, dlt + 64);  // l + 64: source lane l + 64 - j
+                rec0[q] += r0_ok ? r0 : 0.0;
+                pb0[q] += r0_ok ? p0v : 0.0;
+                rec1[q] += r1_ok ? r1 : 0.0;
+                pb1[q] += r1_ok ? p1v : 0.0;
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < PG; ++q) {
+          const int k = k0 + q;
+          if (!act[q]) continue;                                   // wave-uniform: holes / tail pass through unchanged
+          n[k] = relax_update_w(ni[q], dE * qi[q] * g_s[q] + 2.0 * dE * qi[q] * g_r[q], dE * l_s[q] + 2.0 * dE * l_r[q], dt);
+          if (do_ph) {   // per-bin sums through LDS: diagonals first, then the anti-diagonals on top (bins may be shared)
+#pragma unroll
+            for (int s = 0; s < MAXBINS; ++s) {
+              const int w = lane + 64 * s;
+              if (w < NW) { lds[o_A + w] = 0.0; lds[o_B + w] = 0.0; }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane >= 1 && on) { lds[o_A + binD] = em[q]; lds[o_B + binD] = ab[q]; }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 2 * NE - 1) { lds[o_A + binS0] += rec0[q]; lds[o_B + binS0] += pb0[q]; }
+            __builtin_amdgcn_wave_barrier();
+            if (lane + 64 < 2 * NE - 1) { lds[o_A + binS1] += rec1[q]; lds[o_B + binS1] += pb1[q]; }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s = 0; s < MAXBINS; ++s) {
+              const int w = lane + 64 * s;
+              if (w < NW) pb[s][k] = affine_update_w(pb[s][k], lds[o_A + w], lds[o_A + w] - lds[o_B + w], dt);
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int k = 0; k < PB; ++k) {
       if (k >= npx) break;
@@ -142,50 +250,7 @@ __global__ void __launch_bounds__(64 * WAVES) collision_wave_kernel(WaveCollView
       }
       __builtin_amdgcn_wave_barrier();
       double g_s = 0.0, l_s = 0.0, g_r = 0.0, l_r = 0.0;
-      if (STRUCT) {
-        const double Pd = lds[o_wave + binD], Ps0 = lds[o_wave + binS0], Ps1 = lds[o_wave + binS1];
-        double em = 0.0, ab = 0.0, rec0 = 0.0, rec1 = 0.0, pb0 = 0.0, pb1 = 0.0;
-        for (int j = 0; j < NE; ++j) {
-          const double nj = bcast(ni, j), qj = bcast(qi, j);
-          const int row = on ? j * NE + lane : 0;
-          const int dlt = lane - j;
-          if (use_s) {
-            const double K = on ? (STAGED ? lds[row] : ks[row]) : 0.0;
-            const double P = gather(Pd, dlt < 0 ? -dlt : dlt);
-            g_s = fma(K * (dlt < 0 ? 1.0 + P : P), nj, g_s);
-            l_s = fma(K * (dlt > 0 ? 1.0 + P : P), qj, l_s);
-            if (do_ph) {
-              const double v = dE * (ni * K * qj);                 // pair (lane, j); zero on the diagonal (K = 0)
-              const double ve = gather(v, lane + j);               // from lane i = l + j > j: emission into diagonal l
-              const double va = gather(v, j - lane);               // from lane i = j - l < j: absorption
-              if (lane >= 1 && lane + j < NE) em += ve;
-              if (lane >= 1 && j - lane >= 0) ab += va;
-            }
-          }
-          if (use_r) {
-            const double K = on ? (STAGED ? lds[o_kr + row] : kr[row]) : 0.0;
-            const int m = lane + j;
-            const double Pa = gather(Ps0, m), Pb = gather(Ps1, m);
-            const double P = m < 64 ? Pa : Pb;
-            l_r = fma(K * (1.0 + P), nj, l_r);
-            g_r = fma(K * P, qj, g_r);
-            if (do_ph) {
-              const double vr = dE * (ni * K * nj), vp = dE * (qi * K * qj);
-              const double r0 = gather(vr, dlt), p0v = gather(vp, dlt);            // anti-diagonal m = l: source lane l - j
-              const double r1 = gather(vr, dlt + 64), p1v = gather(vp, dlt + 64);  // m = l + 64: source lane l + 64 - j
-              if (dlt >= 0 && dlt < NE) { rec0 += r0; pb0 += p0v; }
-              if (dlt + 64 >= 0 && dlt + 64 < NE) { rec1 += r1; pb1 += p1v; }
-            }
-          }
-        }
-        if (do_ph) {   // per-bin sums: diagonals first, then the anti-diagonals on top (bins may be shared)
-          if (lane >= 1 && on) { lds[o_A + binD] = em; lds[o_B + binD] = ab; }
-          __builtin_amdgcn_wave_barrier();
-          if (lane < 2 * NE - 1) { lds[o_A + binS0] += rec0; lds[o_B + binS0] += pb0; }
-          __builtin_amdgcn_wave_barrier();
-          if (lane + 64 < 2 * NE - 1) { lds[o_A + binS1] += rec1; lds[o_B + binS1] += pb1; }
-        }
-      } else {
+      {
       for (int j = 0; j < NE; ++j) {
         const double nj = bcast(ni, j), qj = bcast(qi, j);
         const int row = on ? j * NE + lane : 0;
@@ -228,6 +293,7 @@ __global__ void __launch_bounds__(64 * WAVES) collision_wave_kernel(WaveCollView
       __builtin_amdgcn_wave_barrier();
     }
 
+    }
     if (on) {
 #pragma unroll
       for (int k = 0; k < PB; ++k)
