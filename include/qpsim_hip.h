@@ -229,6 +229,29 @@ int qp_adi_rect_iface_halo(qp_adi_rect_plan* plan, int32_t dir, int32_t side, in
 /* rows[nfield][nx]: the field row just above (side 0) / below (side 1) the block, consumed by QP_ADI_ENTRY. */
 int qp_adi_rect_set_field_halo(qp_adi_rect_plan* plan, int32_t side, const double* rows, void* stream);
 
+/*
+ * Tiled CN-ADI path for MASKED grids: any mask, any per-face boundary condition, one diffusivity per field.
+ * Replaces the same reference loop as the rectangle path (solver.py:1443-1452 / :1545-1555) on the geometries the
+ * reference actually ships (strips with holes, donuts, GDS shapes: build_laplacian_with_boundaries solver.py:152-212).
+ *   flags, ex, ey, sx, sy   HOST arrays [ny*nx] with the meaning of qp_grid_desc (the plan compresses them into 16-bit
+ *              per-cell codes + a table of distinct boundary terms, classifies the 64 x 64 tiles as empty / clean /
+ *              general and computes the chunk-interface coefficients on the device)
+ * Returns QP_ERR_UNSUPPORTED when r*D is too large for 64-cell chunks to decouple (same 1e-22 criterion as the
+ * rectangle path; r*D <~ 1.3) or when there are more than 1024 distinct boundary-term combinations: the caller then
+ * uses qp_stencil_combine / qp_implicit_sweep.
+ * qp_adi_tile_steps: `nsteps` Peaceman-Rachford steps in place on u[nfield][ny*nx]; cells outside the mask must be 0
+ * and stay 0.  qp_adi_tile_solve: x <- (I - a Ly)^-1 (I - a Lx)^-1 x (preconditioner of the exact-CN iteration).
+ * qp_adi_tile_plan_info: counts[3] = empty, clean, general tiles; far = largest coupling across a chunk.
+ */
+typedef struct qp_adi_tile_plan qp_adi_tile_plan;
+int qp_adi_tile_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, const double* dcoef_host,
+                            const uint8_t* flags, const double* ex, const double* ey, const double* sx, const double* sy,
+                            qp_adi_tile_plan** out);
+int qp_adi_tile_plan_destroy(qp_adi_tile_plan* plan);
+int qp_adi_tile_plan_info(const qp_adi_tile_plan* plan, int32_t* counts, double* far);
+int qp_adi_tile_steps(qp_adi_tile_plan* plan, double* u, int32_t nsteps, void* stream);
+int qp_adi_tile_solve(qp_adi_tile_plan* plan, double* x, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

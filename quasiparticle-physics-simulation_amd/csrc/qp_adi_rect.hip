@@ -28,17 +28,9 @@
 #include <cmath>
 #include <vector>
 
-#include "qp_common.h"
+#include "qp_tile_common.h"
 
 namespace qp {
-
-constexpr int TS = 64;          // tile edge = chunk length
-// far-corner weights of the reduced system below this (relative to its unit diagonal) are dropped: six orders of
-// magnitude under the fp64 rounding of the retained terms
-constexpr double kFarCouplingDrop = 1e-22;
-
-// table slots per (direction, field, chunk variant); each slot is TS doubles
-enum { T_W = 0, T_AWF, T_AWB, T_CM, T_C0, T_CP, T_SRC, T_G, T_H, T_NSLOT };
 
 struct RectDims {
   int ny, nx, nfield;           // LOCAL block extent
@@ -71,101 +63,9 @@ __device__ __forceinline__ int chunk_variant(int p, int P) {
   return (p == 0 ? 1 : 0) | (p == P - 1 ? 2 : 0);
 }
 
-// Tables are written once at plan creation and never by a kernel: read them through the constant address space so
-// that wave-uniform accesses become scalar loads (s_load) and the values feed the FMAs straight from SGPRs.
-typedef const double __attribute__((address_space(4))) * ctab_t;
-
-__device__ __forceinline__ ctab_t as_const(const double* p) {
-  // the address is wave-uniform by construction (kernel arguments and blockIdx only): say so explicitly
-  const unsigned long long a = (unsigned long long)p;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
-  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-  return (ctab_t)(((unsigned long long)hi << 32) | lo);
-}
-
 __device__ __forceinline__ ctab_t table_ptr(const RectView& v, int dir, int b, int variant) {
   return as_const(v.tab + ((((long)dir * v.d.nfield + b) * 4 + variant) * T_NSLOT) * TS);
 }
-
-// Thomas solve of one chunk held in registers; padded entries (k >= chunk length) carry w = 1, aw = 0.
-__device__ __forceinline__ void thomas64(double (&e)[TS], ctab_t t) {
-  double dp = 0.0;
-#pragma unroll
-  for (int k = 0; k < TS; ++k) {
-    dp = fma(t[T_AWF * TS + k], dp, e[k] * t[T_W * TS + k]);
-    e[k] = dp;
-  }
-  double x = 0.0;
-#pragma unroll
-  for (int k = TS - 1; k >= 0; --k) {
-    x = fma(t[T_AWB * TS + k], x, e[k]);
-    e[k] = x;
-  }
-}
-
-// e <- (I + a L) e + a s along the chunk, with neighbour values gl / gr beyond its ends, plus `extra` on valid cells.
-__device__ __forceinline__ void explicit64(double (&e)[TS], double gl, double gr, ctab_t t, double extra) {
-  double prev = gl;
-#pragma unroll
-  for (int k = 0; k < TS; ++k) {
-    const double cur = e[k];
-    const double nxt = (k + 1 < TS) ? e[k + 1] : gr;
-    // `extra` also lands on padded cells (k >= chunk length); those are never stored and meet zero weights in dots64
-    e[k] = fma(t[T_CM * TS + k], prev, fma(t[T_CP * TS + k], nxt, fma(t[T_C0 * TS + k], cur, t[T_SRC * TS + k] + extra)));
-    prev = cur;
-  }
-}
-
-__device__ __forceinline__ void dots64(const double (&e)[TS], ctab_t t, double& yf, double& yl) {
-  double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-  for (int k = 0; k < TS; ++k) {
-    a0 = fma(t[T_G * TS + k], e[k], a0);
-    a1 = fma(t[T_H * TS + k], e[k], a1);
-  }
-  yf = a0;
-  yl = a1;
-}
-
-// In-place transpose of the 64 x 64 tile distributed as v[j] on lane i  ->  v[i] on lane j (its own inverse:
-// lane = column / index = row  <->  lane = row / index = column).  Viewed as 2 x 2 blocks of 32 x 32:
-//   1. v_permlane32_swap exchanges the off-diagonal blocks between the half-waves (registers 0..31 of lanes 32..63
-//      <-> registers 32..63 of lanes 0..31), no memory involved;
-//   2. every block is then transposed inside its own half-wave through a 32 x 33 LDS block, registers 0..31 first,
-//      32..63 second, so only 2 x 32 x 33 doubles (16.5 KiB per wave instead of 33 KiB) are live and no lane-dependent
-//      register index appears.  Pitch 33 keeps the column-wise writes and row-wise reads conflict-free.
-constexpr int HB = 32;
-constexpr int HP = HB + 1;
-constexpr int LDS_DOUBLES = 2 * HB * HP;
-
-__device__ __forceinline__ void swap_half_waves(double& lo_reg, double& hi_reg) {
-  // lanes 32..63 of lo_reg <-> lanes 0..31 of hi_reg
-  const unsigned long long a = __double_as_longlong(lo_reg), b = __double_as_longlong(hi_reg);
-  const auto r0 = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
-  const auto r1 = __builtin_amdgcn_permlane32_swap((unsigned)(a >> 32), (unsigned)(b >> 32), false, false);
-  lo_reg = __longlong_as_double(((unsigned long long)r1[0] << 32) | r0[0]);
-  hi_reg = __longlong_as_double(((unsigned long long)r1[1] << 32) | r0[1]);
-}
-
-__device__ __forceinline__ void transpose64(double (&v)[TS], double* lds, int lane) {
-  const int l = lane & 31;
-  double* blk = lds + (lane >> 5) * (HB * HP);
-#pragma unroll
-  for (int k = 0; k < HB; ++k) swap_half_waves(v[k], v[HB + k]);
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-#pragma unroll
-    for (int k = 0; k < HB; ++k) blk[k * HP + l] = v[half * HB + k];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < HB; ++k) v[half * HB + k] = blk[l * HP + k];
-    __syncthreads();
-  }
-}
-
-struct TileCoord {
-  int b, ty, tx, j0, i0, nr, nc;
-};
 
 __device__ __forceinline__ TileCoord tile_coord(const RectDims& d) {
   TileCoord t;
@@ -179,36 +79,6 @@ __device__ __forceinline__ TileCoord tile_coord(const RectDims& d) {
   t.nr = min(TS, d.ny - t.j0);
   t.nc = min(TS, d.nx - t.i0);
   return t;
-}
-
-// Row r of the tile starts at a wave-uniform address; the lane only adds a 32-bit offset, so the accesses use the
-// SGPR-base + VGPR-offset addressing mode (no 64-bit address arithmetic per row).
-__device__ __forceinline__ void load_cols(const double* __restrict__ base, const TileCoord& t, int nx, int lane,
-                                          double (&v)[TS]) {
-  const double* p = base + (long)t.j0 * nx + t.i0;
-  const unsigned l = (unsigned)lane;
-  if (t.nr == TS && t.nc == TS) {      // interior tile (wave-uniform test): 64 unconditional row-segment loads
-#pragma unroll
-    for (int r = 0; r < TS; ++r) v[r] = (p + (long)r * nx)[l];
-  } else {
-    const bool on = lane < t.nc;
-#pragma unroll
-    for (int r = 0; r < TS; ++r) v[r] = (on && r < t.nr) ? (p + (long)r * nx)[l] : 0.0;
-  }
-}
-
-__device__ __forceinline__ void store_cols(double* __restrict__ base, const TileCoord& t, int nx, int lane,
-                                           const double (&v)[TS]) {
-  double* p = base + (long)t.j0 * nx + t.i0;
-  const unsigned l = (unsigned)lane;
-  if (t.nr == TS && t.nc == TS) {
-#pragma unroll
-    for (int r = 0; r < TS; ++r) (p + (long)r * nx)[l] = v[r];
-  } else if (lane < t.nc) {
-#pragma unroll
-    for (int r = 0; r < TS; ++r)
-      if (r < t.nr) (p + (long)r * nx)[l] = v[r];
-  }
 }
 
 // Values of the solved line just outside chunk p: gl = E_{p-1} (last unknown of the previous chunk),
@@ -378,13 +248,6 @@ __global__ void __launch_bounds__(64) rect_reduced_kernel(RectView v, int dir) {
 // ---------------------------------------------------------------------------------------------------------
 // host side: tables, plan
 // ---------------------------------------------------------------------------------------------------------
-struct DirSpec {
-  int n;          // line length
-  int P;          // chunks
-  double e_lo, e_hi;   // BC diagonal terms of the two end faces (1/dx^2 units)
-  double s_lo, s_hi;   // BC sources of the two end faces
-};
-
 static void chunk_diagonal(const DirSpec& s, double a, int p, int len, std::vector<double>& bdiag) {
   bdiag.assign(len, 0.0);
   for (int k = 0; k < len; ++k) {
@@ -407,8 +270,7 @@ static void solve_chunk(const std::vector<double>& bdiag, double a, std::vector<
   for (int k = len - 2; k >= 0; --k) rhs[k] += a * w[k] * rhs[k + 1];
 }
 
-// fills the T_NSLOT x TS table of chunk `p`; returns g[0], g[last], h[0], h[last] through `ends`
-static void build_chunk_table(const DirSpec& s, double a, int p, double* tab, double ends[4]) {
+void build_chunk_table(const DirSpec& s, double a, int p, double* tab, double ends[4]) {
   const int len = std::min(TS, s.n - p * TS);
   std::vector<double> bd;
   chunk_diagonal(s, a, p, len, bd);

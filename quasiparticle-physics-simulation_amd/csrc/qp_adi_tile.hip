@@ -1,0 +1,602 @@
+// Tiled CN-ADI path for masked grids (any mask, any per-face boundary condition, one diffusivity per field).
+//
+// Same scheme as qp_adi_rect.hip - 64 x 64 tiles, one wave per tile, partition method along each grid line, the
+// carried right-hand side read and written once per sweep - but the lines of a masked grid are all different, so
+// nothing can be tabulated per chunk position.  Instead every cell carries a 16-bit code
+//     bit 0..3  links to the x-, x+, y-, y+ neighbour     bit 4  cell is inside the mask
+//     bit 5..15 index into a small table of boundary terms (ex, ey, sx + sy); 0 = no boundary face
+// stored twice (row-major for x-direction work, column-major for y-direction work: a lane always reads the 128
+// contiguous bytes of its own line), and the tiles are sorted into three classes at plan creation:
+//     empty    no cell inside the mask: never touched (the carried planes stay 0 there)
+//     clean    all 4096 cells inside, all links present, no boundary face: the interior-chunk tables of the
+//              rectangle path apply (wave-uniform scalars), same cost as the rectangle kernels
+//     general  everything else: pivots, spikes and the explicit operator are computed per lane from the codes
+//              (one fp64 division per cell and pass; these kernels keep the Thomas coefficients of a whole line
+//              in registers and run at one wave per SIMD)
+// Clean and general tiles are launched as separate kernels over their tile lists.
+//
+// Coupling between the chunks of a line: as in the rectangle path's "decoupled" regime.  With
+//     x_p = y_p + wm_first E_{p-1} g_p + wp_last F_{p+1} h_p,        g_p, h_p = first / last column of A_p^-1
+// the far corners g_p[last], h_p[first] are checked at plan creation to be below 1e-22 (else the plan is refused and
+// the caller falls back to the per-line kernels), so each interface is the 2 x 2 system
+//     E_p - s_p F_{p+1} = y_p[last],   F_{p+1} - t_{p+1} E_p = y_{p+1}[first],
+//     s_p = wp_last h_p[last],  t_p = wm_first g_p[first]
+// whose coefficients are per (field, line, chunk) constants computed once on the device (`coef`), and whose
+// right-hand sides (`iface`) are produced by the preceding sweep kernel as a by-product.
+#include <cstring>
+#include <map>
+#include <tuple>
+#include <vector>
+
+#include "qp_tile_common.h"
+
+namespace qp {
+
+constexpr int kCodeIdxShift = 5;
+constexpr int kMaxBc = 1024;            // boundary-term table entries (24 B each, staged in LDS by general tiles)
+
+struct TileView {
+  int ny, nx, nfield;
+  int py, px;                   // tiles per column / per row
+  int pny, pnx;                 // padded extents of the code planes (py * 64, px * 64)
+  const double* alpha;          // [nfield] r D
+  const double* tab;            // [nfield][T_NSLOT][TS] interior-chunk tables (clean tiles)
+  const uint16_t* code_r;       // [pny][pnx]
+  const uint16_t* code_c;       // [pnx][pny]
+  const double* bct;            // [nbc][3] (ex, ey, sx + sy)
+  int nbc;
+  double* iface[2];             // per dir [nfield][2P+2][nlines]: row 2p+1 = y_p[first], row 2p+2 = y_p[last]
+  double* coef[2];              // same shape: row 2p+1 = t_p, row 2p+2 = s_p
+  const int32_t* tiles[2];      // [0] clean, [1] general: (ty << 16) | tx
+  int ntiles[2];
+};
+
+template <int DIR> struct Bits {
+  static constexpr unsigned LM = DIR == 0 ? QP_FLAG_LINK_XM : QP_FLAG_LINK_YM;
+  static constexpr unsigned LP = DIR == 0 ? QP_FLAG_LINK_XP : QP_FLAG_LINK_YP;
+};
+
+// code of cell k of the lane's line (two codes per dword)
+__device__ __forceinline__ unsigned code_at(const unsigned (&cw)[TS / 2], int k) {
+  return (k & 1) ? (cw[k >> 1] >> 16) : (cw[k >> 1] & 0xffffu);
+}
+
+__device__ __forceinline__ void load_codes(const uint16_t* line, unsigned (&cw)[TS / 2]) {
+  const uint4* p = reinterpret_cast<const uint4*>(line);      // 128-byte aligned by construction
+#pragma unroll
+  for (int q = 0; q < TS / 8; ++q) {
+    const uint4 w = p[q];
+    cw[4 * q] = w.x; cw[4 * q + 1] = w.y; cw[4 * q + 2] = w.z; cw[4 * q + 3] = w.w;
+  }
+}
+
+// (I - a L) x = e along the lane's chunk with neighbour values gl / gr beyond its ends.
+template <int DIR>
+__device__ __forceinline__ void solve_general(double (&e)[TS], const unsigned (&cw)[TS / 2], double a, const double* bct,
+                                              double gl, double gr) {
+  double c[TS];
+  double wm = (code_at(cw, 0) & Bits<DIR>::LM) ? a : 0.0;
+  e[0] = fma(wm, gl, e[0]);
+  double cprev = 0.0, dprev = 0.0;
+#pragma unroll
+  for (int k = 0; k < TS; ++k) {
+    const unsigned code = code_at(cw, k);
+    const double wp = (code & Bits<DIR>::LP) ? a : 0.0;
+    const double bd = a * bct[3 * (code >> kCodeIdxShift) + DIR];
+    if (k == TS - 1) e[k] = fma(wp, gr, e[k]);
+    const double inv = 1.0 / fma(-wm, cprev, 1.0 + wm + wp + bd);
+    cprev = wp * inv;
+    c[k] = cprev;
+    dprev = fma(wm, dprev, e[k]) * inv;
+    e[k] = dprev;
+    wm = wp;
+  }
+  double x = 0.0;
+#pragma unroll
+  for (int k = TS - 1; k >= 0; --k) {
+    x = fma(c[k], x, e[k]);
+    e[k] = x;
+  }
+}
+
+// e <- (I + a L) e + a (sx + sy) along the lane's chunk
+template <int DIR>
+__device__ __forceinline__ void explicit_general(double (&e)[TS], const unsigned (&cw)[TS / 2], double a, const double* bct,
+                                                 double gl, double gr) {
+  double prev = gl;
+  double wm = (code_at(cw, 0) & Bits<DIR>::LM) ? a : 0.0;
+#pragma unroll
+  for (int k = 0; k < TS; ++k) {
+    const unsigned code = code_at(cw, k);
+    const double wp = (code & Bits<DIR>::LP) ? a : 0.0;
+    const unsigned idx = code >> kCodeIdxShift;
+    const double bd = a * bct[3 * idx + DIR], src = a * bct[3 * idx + 2];
+    const double cur = e[k];
+    const double nxt = (k + 1 < TS) ? e[k + 1] : gr;
+    e[k] = fma(wm, prev - cur, fma(wp, nxt - cur, fma(-bd, cur, cur + src)));
+    prev = cur;
+    wm = wp;
+  }
+}
+
+// First and last entry of A_p^-1 e (chunk-local system, couplings to the neighbouring chunks dropped), plus the
+// interface coefficients s = wp_last h[last], t = wm_first g[first] (by-products of the two eliminations).
+template <int DIR>
+__device__ __forceinline__ void ends_general(const double (&e)[TS], const unsigned (&cw)[TS / 2], double a, const double* bct,
+                                             double& yf, double& yl, double& s, double& t) {
+  double wm = (code_at(cw, 0) & Bits<DIR>::LM) ? a : 0.0;
+  double wq = (code_at(cw, TS - 1) & Bits<DIR>::LP) ? a : 0.0;
+  double cf = 0.0, df = 0.0, cb = 0.0, db = 0.0;
+#pragma unroll
+  for (int k = 0; k < TS; ++k) {
+    {  // forward elimination, cell k
+      const unsigned code = code_at(cw, k);
+      const double wp = (code & Bits<DIR>::LP) ? a : 0.0;
+      const double bd = a * bct[3 * (code >> kCodeIdxShift) + DIR];
+      const double inv = 1.0 / fma(-wm, cf, 1.0 + wm + wp + bd);
+      cf = wp * inv;
+      df = fma(wm, df, e[k]) * inv;
+      wm = wp;
+    }
+    {  // backward elimination, cell TS-1-k
+      const int kb = TS - 1 - k;
+      const unsigned code = code_at(cw, kb);
+      const double wl = (code & Bits<DIR>::LM) ? a : 0.0;
+      const double bd = a * bct[3 * (code >> kCodeIdxShift) + DIR];
+      const double inv = 1.0 / fma(-wq, cb, 1.0 + wl + wq + bd);
+      cb = wl * inv;
+      db = fma(wq, db, e[kb]) * inv;
+      wq = wl;
+    }
+  }
+  yl = df;
+  yf = db;
+  s = cf;
+  t = cb;
+}
+
+// Neighbour values of the solved line just outside chunk p of `line`: gl = E_{p-1}, gr = F_{p+1}.
+template <int DIR>
+__device__ __forceinline__ void tile_ghosts(const TileView& v, int b, int p, long line, bool on, double& gl, double& gr) {
+  const int P = DIR == 0 ? v.px : v.py;
+  const long nl = DIR == 0 ? v.ny : v.nx;
+  gl = 0.0;
+  gr = 0.0;
+  if (!on) return;
+  const long base = (long)b * (2 * P + 2) * nl + line;
+  const double* ir = v.iface[DIR] + base;
+  const double* cf = v.coef[DIR] + base;
+  if (p > 0) {
+    const double yl = ir[(long)(2 * p) * nl], s = cf[(long)(2 * p) * nl];
+    const double yf = ir[(long)(2 * p + 1) * nl], t = cf[(long)(2 * p + 1) * nl];
+    gl = fma(s, yf, yl) / fma(-s, t, 1.0);
+  }
+  if (p < P - 1) {
+    const double yl = ir[(long)(2 * p + 2) * nl], s = cf[(long)(2 * p + 2) * nl];
+    const double yf = ir[(long)(2 * p + 3) * nl], t = cf[(long)(2 * p + 3) * nl];
+    gr = fma(t, yl, yf) / fma(-s, t, 1.0);
+  }
+}
+
+template <bool GEN>
+__device__ __forceinline__ TileCoord tile_of(const TileView& v) {
+  TileCoord t;
+  const int id = blockIdx.x;
+  t.b = id % v.nfield;                          // fields of one tile are neighbours in launch order: shared codes hit L2
+  const int packed = v.tiles[GEN ? 1 : 0][id / v.nfield];
+  t.ty = packed >> 16;
+  t.tx = packed & 0xffff;
+  t.j0 = t.ty * TS;
+  t.i0 = t.tx * TS;
+  t.nr = min(TS, v.ny - t.j0);
+  t.nc = min(TS, v.nx - t.i0);
+  return t;
+}
+
+__device__ __forceinline__ void stage_bct(const TileView& v, double* dst, int lane) {
+  for (int q = lane; q < 3 * v.nbc; q += 64) dst[q] = v.bct[q];
+  __syncthreads();
+}
+
+// x-kernel: finish the x-solve, [apply (I + a Lx) . + a S], store, chunk-local eliminations along y -> iface[1]
+template <bool GEN, bool EXPLICIT>
+__global__ void __launch_bounds__(64) tile_x_kernel(TileView v, double* __restrict__ buf) {
+  __shared__ double lds[LDS_DOUBLES];
+  extern __shared__ double bct[];
+  const int lane = threadIdx.x;
+  const TileCoord t = tile_of<GEN>(v);
+  if (GEN) stage_bct(v, bct, lane);
+  const long ncell = (long)v.ny * v.nx;
+  double* plane = buf + (long)t.b * ncell;
+  const double a = as_const(v.alpha)[t.b];
+  const ctab_t tab = as_const(v.tab + (long)t.b * T_NSLOT * TS);
+  double e[TS];
+  load_cols(plane, t, v.nx, lane, e);
+  transpose64(e, lds, lane);
+  double gl, gr;
+  tile_ghosts<0>(v, t.b, t.tx, t.j0 + lane, lane < t.nr, gl, gr);
+  if (GEN) {
+    unsigned cw[TS / 2];
+    load_codes(v.code_r + (long)(t.j0 + lane) * v.pnx + t.i0, cw);
+    solve_general<0>(e, cw, a, bct, gl, gr);
+    if (EXPLICIT) explicit_general<0>(e, cw, a, bct, gl, gr);
+  } else {
+    e[0] = fma(a, gl, e[0]);
+    e[TS - 1] = fma(a, gr, e[TS - 1]);
+    thomas64(e, tab);
+    if (EXPLICIT) explicit64(e, gl, gr, tab, 0.0);
+  }
+  transpose64(e, lds, lane);
+  store_cols(plane, t, v.nx, lane, e);
+  double yf, yl;
+  if (GEN) {
+    unsigned cw[TS / 2];
+    double s, tt;
+    load_codes(v.code_c + (long)(t.i0 + lane) * v.pny + t.j0, cw);
+    ends_general<1>(e, cw, a, bct, yf, yl, s, tt);
+  } else {
+    dots64(e, tab, yf, yl);
+  }
+  if (lane < t.nc) {
+    double* ir = v.iface[1] + (long)t.b * (2 * v.py + 2) * v.nx;
+    ir[(long)(2 * t.ty + 1) * v.nx + t.i0 + lane] = yf;
+    ir[(long)(2 * t.ty + 2) * v.nx + t.i0 + lane] = yl;
+  }
+}
+
+// y-kernel.  MODE 0 (entry): src = u -> rhs1 = (I + a Ly) u + a S;  MODE 1 (carry): y-solve, rhs1' of the next step;
+//            MODE 2 (exit): y-solve, dst = u';  MODE 3 (reduce): only the x-eliminations of src (nothing stored).
+//            MODE 0, 1, 3 end with the chunk-local eliminations along x -> iface[0]
+template <bool GEN, int MODE>
+__global__ void __launch_bounds__(64) tile_y_kernel(TileView v, const double* src, double* dst) {   // src may alias dst
+  __shared__ double lds[LDS_DOUBLES];
+  extern __shared__ double bct[];
+  const int lane = threadIdx.x;
+  const TileCoord t = tile_of<GEN>(v);
+  if (GEN) stage_bct(v, bct, lane);
+  const long ncell = (long)v.ny * v.nx;
+  const double* splane = src + (long)t.b * ncell;
+  double* dplane = dst + (long)t.b * ncell;
+  const double a = as_const(v.alpha)[t.b];
+  const ctab_t tab = as_const(v.tab + (long)t.b * T_NSLOT * TS);
+  const int col = t.i0 + lane;
+  const bool col_on = lane < t.nc;
+  double e[TS];
+  load_cols(splane, t, v.nx, lane, e);
+  double gu = 0.0, gd = 0.0;
+  if (MODE == 0) {
+    if (col_on && t.ty > 0) gu = splane[(long)(t.j0 - 1) * v.nx + col];
+    if (col_on && t.j0 + TS < v.ny) gd = splane[(long)(t.j0 + TS) * v.nx + col];
+  } else if (MODE != 3) {
+    tile_ghosts<1>(v, t.b, t.ty, col, col_on, gu, gd);
+  }
+  if (GEN) {
+    if (MODE != 3) {
+      unsigned cw[TS / 2];
+      load_codes(v.code_c + (long)(t.i0 + lane) * v.pny + t.j0, cw);
+      if (MODE != 0) solve_general<1>(e, cw, a, bct, gu, gd);
+      if (MODE != 2) explicit_general<1>(e, cw, a, bct, gu, gd);
+    }
+  } else {
+    if (MODE == 1 || MODE == 2) {
+      e[0] = fma(a, gu, e[0]);
+      e[TS - 1] = fma(a, gd, e[TS - 1]);
+      thomas64(e, tab);
+    }
+    if (MODE == 0 || MODE == 1) explicit64(e, gu, gd, tab, 0.0);
+  }
+  if (MODE != 3) store_cols(dplane, t, v.nx, lane, e);
+  if (MODE == 2) return;
+  transpose64(e, lds, lane);
+  double yf, yl;
+  if (GEN) {
+    unsigned cw[TS / 2];
+    double s, tt;
+    load_codes(v.code_r + (long)(t.j0 + lane) * v.pnx + t.i0, cw);
+    ends_general<0>(e, cw, a, bct, yf, yl, s, tt);
+  } else {
+    dots64(e, tab, yf, yl);
+  }
+  if (lane < t.nr) {
+    double* ir = v.iface[0] + (long)t.b * (2 * v.px + 2) * v.ny;
+    ir[(long)(2 * t.tx + 1) * v.ny + t.j0 + lane] = yf;
+    ir[(long)(2 * t.tx + 2) * v.ny + t.j0 + lane] = yl;
+  }
+}
+
+// Plan creation: interface coefficients (s, t) of every chunk of every non-empty tile in both directions, and the
+// largest far coupling (atomic max over the bit pattern of a non-negative double).
+__global__ void __launch_bounds__(64) tile_setup_kernel(TileView v, int cls, unsigned long long* far_bits) {
+  extern __shared__ double bct[];
+  const int lane = threadIdx.x;
+  TileCoord t;
+  {
+    const int id = blockIdx.x;
+    t.b = id % v.nfield;
+    const int packed = v.tiles[cls][id / v.nfield];
+    t.ty = packed >> 16;
+    t.tx = packed & 0xffff;
+    t.j0 = t.ty * TS;
+    t.i0 = t.tx * TS;
+    t.nr = min(TS, v.ny - t.j0);
+    t.nc = min(TS, v.nx - t.i0);
+  }
+  stage_bct(v, bct, lane);
+  const double a = v.alpha[t.b];
+  double far = 0.0;
+  for (int dir = 0; dir < 2; ++dir) {
+    unsigned cw[TS / 2];
+    if (dir == 0) load_codes(v.code_r + (long)(t.j0 + lane) * v.pnx + t.i0, cw);
+    else load_codes(v.code_c + (long)(t.i0 + lane) * v.pny + t.j0, cw);
+    double e[TS];
+#pragma unroll
+    for (int k = 0; k < TS; ++k) e[k] = k == 0 ? 1.0 : 0.0;
+    double yf, yl, s, tt, yf2, yl2;
+    const unsigned c0 = code_at(cw, 0), c1 = code_at(cw, TS - 1);
+    double wm0, wp1;
+    if (dir == 0) {
+      ends_general<0>(e, cw, a, bct, yf, yl, s, tt);
+      e[0] = 0.0; e[TS - 1] = 1.0;
+      double s2, t2;
+      ends_general<0>(e, cw, a, bct, yf2, yl2, s2, t2);
+      wm0 = (c0 & QP_FLAG_LINK_XM) ? a : 0.0;
+      wp1 = (c1 & QP_FLAG_LINK_XP) ? a : 0.0;
+    } else {
+      ends_general<1>(e, cw, a, bct, yf, yl, s, tt);
+      e[0] = 0.0; e[TS - 1] = 1.0;
+      double s2, t2;
+      ends_general<1>(e, cw, a, bct, yf2, yl2, s2, t2);
+      wm0 = (c0 & QP_FLAG_LINK_YM) ? a : 0.0;
+      wp1 = (c1 & QP_FLAG_LINK_YP) ? a : 0.0;
+    }
+    far = fmax(far, fmax(fabs(wm0 * yl), fabs(wp1 * yf2)));      // wm_first g[last], wp_last h[first]
+    const int P = dir == 0 ? v.px : v.py, p = dir == 0 ? t.tx : t.ty;
+    const long nl = dir == 0 ? v.ny : v.nx;
+    const long line = dir == 0 ? t.j0 + lane : t.i0 + lane;
+    if (lane < (dir == 0 ? t.nr : t.nc)) {
+      double* cf = v.coef[dir] + (long)t.b * (2 * P + 2) * nl + line;
+      cf[(long)(2 * p + 1) * nl] = tt;
+      cf[(long)(2 * p + 2) * nl] = s;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) far = fmax(far, __shfl_xor(far, off));
+  if (lane == 0) atomicMax(far_bits, (unsigned long long)__double_as_longlong(far));
+}
+
+}  // namespace qp
+
+struct qp_adi_tile_plan {
+  qp::TileView view;
+  std::vector<void*> allocs;
+  double* d_work = nullptr;
+  long ncell = 0;
+  int counts[3] = {0, 0, 0};       // empty, clean, general tiles
+  size_t bct_bytes = 0;
+  double far = 0.0;
+};
+
+extern "C" {
+
+int qp_adi_tile_plan_destroy(qp_adi_tile_plan* plan) {
+  if (!plan) return QP_OK;
+  for (void* p : plan->allocs) (void)hipFree(p);
+  delete plan;
+  return QP_OK;
+}
+
+int qp_adi_tile_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, const double* dcoef_host,
+                            const uint8_t* flags, const double* ex, const double* ey, const double* sx, const double* sy,
+                            qp_adi_tile_plan** out) {
+  QP_REQUIRE(out != nullptr, "out is NULL");
+  *out = nullptr;
+  QP_REQUIRE(ny > 0 && nx > 0 && nfield > 0, "ny, nx, nfield must be positive");
+  QP_REQUIRE(r > 0.0 && dcoef_host && flags && ex && ey && sx && sy, "r must be positive; host arrays non-NULL");
+  using namespace qp;
+  const int py = (ny + TS - 1) / TS, px = (nx + TS - 1) / TS;
+  QP_REQUIRE(py < 32768 && px < 65536, "grid too large for the packed tile index");
+  const int pny = py * TS, pnx = px * TS;
+  for (int b = 0; b < nfield; ++b) QP_REQUIRE(dcoef_host[b] >= 0.0, "diffusion coefficients must be >= 0");
+
+  // codes and the boundary-term table
+  std::map<std::tuple<double, double, double>, int> bc_index;
+  std::vector<double> bct = {0.0, 0.0, 0.0};
+  bc_index[std::make_tuple(0.0, 0.0, 0.0)] = 0;
+  std::vector<uint16_t> code_r((size_t)pny * pnx, 0), code_c((size_t)pnx * pny, 0);
+  for (int j = 0; j < ny; ++j) {
+    for (int i = 0; i < nx; ++i) {
+      const size_t p = (size_t)j * nx + i;
+      const unsigned f = flags[p];
+      if (!(f & QP_FLAG_ACTIVE)) continue;
+      // links must be mutual and stay inside the mask: the sweeps use wm_k = wp_{k-1}
+      const bool ok = (!(f & QP_FLAG_LINK_XM) || (i > 0 && (flags[p - 1] & QP_FLAG_LINK_XP))) &&
+                      (!(f & QP_FLAG_LINK_XP) || (i < nx - 1 && (flags[p + 1] & QP_FLAG_LINK_XM))) &&
+                      (!(f & QP_FLAG_LINK_YM) || (j > 0 && (flags[p - nx] & QP_FLAG_LINK_YP))) &&
+                      (!(f & QP_FLAG_LINK_YP) || (j < ny - 1 && (flags[p + nx] & QP_FLAG_LINK_YM)));
+      QP_REQUIRE(ok, "link flags are not mutual");
+      int idx = 0;
+      const double s = sx[p] + sy[p];
+      if (ex[p] != 0.0 || ey[p] != 0.0 || s != 0.0) {
+        const auto key = std::make_tuple(ex[p], ey[p], s);
+        auto it = bc_index.find(key);
+        if (it == bc_index.end()) {
+          idx = (int)bc_index.size();
+          if (idx >= kMaxBc) {
+            set_error("qp_adi_tile_plan_create: more than %d distinct boundary-term combinations", kMaxBc);
+            return QP_ERR_UNSUPPORTED;
+          }
+          bc_index[key] = idx;
+          bct.push_back(ex[p]);
+          bct.push_back(ey[p]);
+          bct.push_back(s);
+        } else {
+          idx = it->second;
+        }
+      }
+      const uint16_t code = (uint16_t)((f & 31u) | ((unsigned)idx << kCodeIdxShift));
+      code_r[(size_t)j * pnx + i] = code;
+      code_c[(size_t)i * pny + j] = code;
+    }
+  }
+  // tile classes
+  std::vector<int32_t> lists[2];
+  int counts[3] = {0, 0, 0};
+  for (int ty = 0; ty < py; ++ty) {
+    for (int tx = 0; tx < px; ++tx) {
+      bool any = false, clean = true;
+      for (int j = ty * TS; j < ty * TS + TS; ++j) {
+        const uint16_t* row = &code_r[(size_t)j * pnx + tx * TS];
+        for (int k = 0; k < TS; ++k) {
+          any = any || row[k] != 0;
+          clean = clean && row[k] == 31u;
+        }
+      }
+      if (!any) { counts[0]++; continue; }
+      const int cls = clean ? 0 : 1;
+      counts[1 + cls]++;
+      lists[cls].push_back((ty << 16) | tx);
+    }
+  }
+  // interior-chunk tables of the rectangle path (chunk 1 of a 3-chunk line; end faces irrelevant)
+  std::vector<double> alpha(nfield), tab((size_t)nfield * T_NSLOT * TS);
+  const DirSpec spec{3 * TS, 3, 0.0, 0.0, 0.0, 0.0};
+  for (int b = 0; b < nfield; ++b) {
+    alpha[b] = r * dcoef_host[b];
+    double ends[4];
+    build_chunk_table(spec, alpha[b], 1, &tab[(size_t)b * T_NSLOT * TS], ends);
+  }
+
+  auto* plan = new qp_adi_tile_plan();
+  TileView& v = plan->view;
+  v.ny = ny; v.nx = nx; v.nfield = nfield; v.py = py; v.px = px; v.pny = pny; v.pnx = pnx;
+  v.nbc = (int)bc_index.size();
+  plan->ncell = (long)ny * nx;
+  plan->bct_bytes = bct.size() * sizeof(double);
+  for (int k = 0; k < 3; ++k) plan->counts[k] = counts[k];
+  bool ok = true;
+  auto upload = [&](const void* h, size_t bytes) -> void* {
+    void* d = nullptr;
+    if (!ok) return nullptr;
+    if (hipMalloc(&d, bytes ? bytes : 8) != hipSuccess) { ok = false; return nullptr; }
+    plan->allocs.push_back(d);
+    if (bytes && hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) != hipSuccess) ok = false;
+    return d;
+  };
+  auto zalloc = [&](size_t bytes) -> void* {
+    void* d = nullptr;
+    if (!ok) return nullptr;
+    if (hipMalloc(&d, bytes ? bytes : 8) != hipSuccess) { ok = false; return nullptr; }
+    plan->allocs.push_back(d);
+    if (hipMemset(d, 0, bytes ? bytes : 8) != hipSuccess) ok = false;
+    return d;
+  };
+  v.alpha = (const double*)upload(alpha.data(), alpha.size() * sizeof(double));
+  v.tab = (const double*)upload(tab.data(), tab.size() * sizeof(double));
+  v.code_r = (const uint16_t*)upload(code_r.data(), code_r.size() * sizeof(uint16_t));
+  v.code_c = (const uint16_t*)upload(code_c.data(), code_c.size() * sizeof(uint16_t));
+  v.bct = (const double*)upload(bct.data(), bct.size() * sizeof(double));
+  for (int c = 0; c < 2; ++c) {
+    v.tiles[c] = (const int32_t*)upload(lists[c].data(), lists[c].size() * sizeof(int32_t));
+    v.ntiles[c] = (int)lists[c].size();
+  }
+  for (int d = 0; d < 2; ++d) {
+    const size_t nl = d == 0 ? ny : nx, P = d == 0 ? px : py;
+    v.iface[d] = (double*)zalloc((size_t)nfield * (2 * P + 2) * nl * sizeof(double));
+    v.coef[d] = (double*)zalloc((size_t)nfield * (2 * P + 2) * nl * sizeof(double));
+  }
+  plan->d_work = (double*)zalloc((size_t)nfield * plan->ncell * sizeof(double));
+  unsigned long long* d_far = (unsigned long long*)zalloc(sizeof(unsigned long long));
+  if (!ok) {
+    (void)hipGetLastError();
+    qp_adi_tile_plan_destroy(plan);
+    set_error("qp_adi_tile_plan_create: device allocation or upload failed");
+    return QP_ERR_ALLOC;
+  }
+  for (int c = 0; c < 2; ++c)
+    if (v.ntiles[c] > 0)
+      hipLaunchKernelGGL(tile_setup_kernel, dim3((unsigned)((long)v.ntiles[c] * nfield)), dim3(64), plan->bct_bytes, 0, v,
+                         c, d_far);
+  unsigned long long far_bits = 0;
+  if (hipMemcpy(&far_bits, d_far, sizeof(far_bits), hipMemcpyDeviceToHost) != hipSuccess || hipGetLastError() != hipSuccess) {
+    qp_adi_tile_plan_destroy(plan);
+    set_error("qp_adi_tile_plan_create: setup kernel failed");
+    return QP_ERR_LAUNCH;
+  }
+  double far;
+  memcpy(&far, &far_bits, sizeof(far));
+  plan->far = far;
+  if (!(far < kFarCouplingDrop)) {
+    qp_adi_tile_plan_destroy(plan);
+    set_error("qp_adi_tile_plan_create: r*D too large for the tiled path (coupling across a 64-cell chunk %.3g, limit %.0e)",
+              far, kFarCouplingDrop);
+    return QP_ERR_UNSUPPORTED;
+  }
+  *out = plan;
+  return QP_OK;
+}
+
+int qp_adi_tile_plan_info(const qp_adi_tile_plan* plan, int32_t* counts, double* far) {
+  QP_REQUIRE(plan && counts, "plan and counts must be non-NULL");
+  for (int k = 0; k < 3; ++k) counts[k] = plan->counts[k];
+  if (far) *far = plan->far;
+  return QP_OK;
+}
+
+}  // extern "C"
+
+namespace qp {
+
+template <bool EXPLICIT>
+static void launch_x(const qp_adi_tile_plan* plan, double* buf, hipStream_t stream) {
+  const TileView& v = plan->view;
+  if (v.ntiles[0] > 0)
+    hipLaunchKernelGGL((tile_x_kernel<false, EXPLICIT>), dim3((unsigned)((long)v.ntiles[0] * v.nfield)), dim3(64), 0, stream,
+                       v, buf);
+  if (v.ntiles[1] > 0)
+    hipLaunchKernelGGL((tile_x_kernel<true, EXPLICIT>), dim3((unsigned)((long)v.ntiles[1] * v.nfield)), dim3(64),
+                       plan->bct_bytes, stream, v, buf);
+}
+
+template <int MODE>
+static void launch_y(const qp_adi_tile_plan* plan, const double* src, double* dst, hipStream_t stream) {
+  const TileView& v = plan->view;
+  if (v.ntiles[0] > 0)
+    hipLaunchKernelGGL((tile_y_kernel<false, MODE>), dim3((unsigned)((long)v.ntiles[0] * v.nfield)), dim3(64), 0, stream, v,
+                       src, dst);
+  if (v.ntiles[1] > 0)
+    hipLaunchKernelGGL((tile_y_kernel<true, MODE>), dim3((unsigned)((long)v.ntiles[1] * v.nfield)), dim3(64),
+                       plan->bct_bytes, stream, v, src, dst);
+}
+
+}  // namespace qp
+
+extern "C" {
+
+// `nsteps` Peaceman-Rachford steps in place on u[nfield][ny*nx] (cells outside the mask must be, and stay, 0).
+int qp_adi_tile_steps(qp_adi_tile_plan* plan, double* u, int32_t nsteps, void* stream_) {
+  QP_REQUIRE(plan && u, "plan and u must be non-NULL");
+  QP_REQUIRE(nsteps >= 1, "nsteps must be >= 1");
+  using namespace qp;
+  hipStream_t stream = (hipStream_t)stream_;
+  double* w = plan->d_work;
+  launch_y<0>(plan, u, w, stream);
+  for (int s = 0; s < nsteps; ++s) {
+    launch_x<true>(plan, w, stream);
+    if (s + 1 < nsteps) launch_y<1>(plan, w, w, stream);
+    else launch_y<2>(plan, w, u, stream);
+  }
+  return check_launch("qp_adi_tile_steps");
+}
+
+// x <- (I - a Ly)^-1 (I - a Lx)^-1 x in place (ADI preconditioner of the unsplit CN matrix); x = 0 outside the mask.
+int qp_adi_tile_solve(qp_adi_tile_plan* plan, double* x, void* stream_) {
+  QP_REQUIRE(plan && x, "plan and x must be non-NULL");
+  using namespace qp;
+  hipStream_t stream = (hipStream_t)stream_;
+  launch_y<3>(plan, x, x, stream);
+  launch_x<false>(plan, x, stream);
+  launch_y<2>(plan, x, x, stream);
+  return check_launch("qp_adi_tile_solve");
+}
+
+}  // extern "C"

@@ -35,6 +35,10 @@ class RectPlan(C.Structure):
     """Opaque ``qp_adi_rect_plan``; only ever handled by pointer."""
 
 
+class TilePlan(C.Structure):
+    """Opaque ``qp_adi_tile_plan``; only ever handled by pointer."""
+
+
 # name -> (restype, argtypes); must list every symbol declared in include/qpsim_hip.h
 SIGNATURES = {
     "qp_version": (C.c_int, []),
@@ -68,6 +72,12 @@ SIGNATURES = {
     "qp_adi_rect_phase": (C.c_int, [C.POINTER(RectPlan), C.c_int32, c_dp, c_dp]),
     "qp_adi_rect_iface_halo": (C.c_int, [C.POINTER(RectPlan), C.c_int32, C.c_int32, C.c_int32, c_dp, c_dp]),
     "qp_adi_rect_set_field_halo": (C.c_int, [C.POINTER(RectPlan), C.c_int32, c_dp, c_dp]),
+    "qp_adi_tile_plan_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.POINTER(C.c_double), c_dp, c_dp,
+                                          c_dp, c_dp, c_dp, C.POINTER(C.POINTER(TilePlan))]),
+    "qp_adi_tile_plan_destroy": (C.c_int, [C.POINTER(TilePlan)]),
+    "qp_adi_tile_plan_info": (C.c_int, [C.POINTER(TilePlan), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+    "qp_adi_tile_steps": (C.c_int, [C.POINTER(TilePlan), c_dp, C.c_int32, c_dp]),
+    "qp_adi_tile_solve": (C.c_int, [C.POINTER(TilePlan), c_dp, c_dp]),
 }
 
 
@@ -99,11 +109,13 @@ def load():
 
 
 class QPHipError(RuntimeError):
-    pass
+    status = 0
 
 
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = load().qp_last_error()
-        raise QPHipError(f"{what or 'libqpsim_hip call'} failed with status {rc}: "
+        err = QPHipError(f"{what or 'libqpsim_hip call'} failed with status {rc}: "
                          f"{msg.decode(errors='replace') if msg else ''}")
+        err.status = rc
+        raise err

@@ -227,11 +227,45 @@ class RectPlan:
             pass
 
 
+class TilePlan:
+    """Owner of a ``qp_adi_tile_plan`` (tiled ADI path for masked grids with one diffusivity per field)."""
+
+    def __init__(self, lib, geom: CompiledGeometry, nfield, r, dcoef):
+        self._lib = lib
+        self._h = C.POINTER(_hip.TilePlan)()
+        ny, nx = geom.mask.shape
+        dc = (C.c_double * nfield)(*[float(v) for v in dcoef])
+        host = [np.ascontiguousarray(geom.flags, dtype=np.uint8)] + [
+            np.ascontiguousarray(a, dtype=np.float64) for a in (geom.ex, geom.ey, geom.sx, geom.sy)]
+        _hip.check(lib.qp_adi_tile_plan_create(ny, nx, nfield, float(r), dc, *[a.ctypes.data for a in host],
+                                               C.byref(self._h)), "qp_adi_tile_plan_create")
+        counts = (C.c_int32 * 3)()
+        far = C.c_double()
+        _hip.check(lib.qp_adi_tile_plan_info(self._h, counts, C.byref(far)), "qp_adi_tile_plan_info")
+        self.tile_counts = {"empty": counts[0], "clean": counts[1], "general": counts[2]}
+        self.far_coupling = far.value
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            self._lib.qp_adi_tile_plan_destroy(self._h)
+            self._h = C.POINTER(_hip.TilePlan)()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DiffusionOperator:
     """(I - r L_x), (I - r L_y) and friends for one time step size on a batch of fields."""
 
     def __init__(self, engine: "Engine", nfield: int, dt: float, dcoef=None, dfield=None, allow_fast: bool = True,
-                 force_banded: bool = False):
+                 force_banded: bool = False, allow_tile: bool = True):
         torch = engine.torch
         self.engine = engine
         self.nfield = int(nfield)
@@ -252,6 +286,18 @@ class DiffusionOperator:
             with torch.cuda.device(engine.device):
                 self.rect = RectPlan(engine.lib, g.ny, g.nx, self.nfield, self.r, np.asarray(dcoef, dtype=float),
                                      sides[0], sides[1], force_banded=force_banded)
+        # any other geometry with one D per field -> tiled kernels driven by per-cell codes, unless r*D is too large for
+        # 64-cell chunks to decouple (then the per-line kernels below remain)
+        self.tile = None
+        self.tile_refused = None
+        if self.rect is None and allow_fast and allow_tile and dcoef is not None and self.dt > 0.0:
+            with torch.cuda.device(engine.device):
+                try:
+                    self.tile = TilePlan(engine.lib, engine.geom, self.nfield, self.r, np.asarray(dcoef, dtype=float))
+                except _hip.QPHipError as exc:
+                    if exc.status != -3:      # QP_ERR_UNSUPPORTED
+                        raise
+                    self.tile_refused = str(exc)
 
 
 class Engine:
@@ -315,13 +361,16 @@ class Engine:
         if op.rect is not None:
             _hip.check(self.lib.qp_adi_rect_steps(op.rect.handle, _ptr(u), int(nsteps), self.stream), "qp_adi_rect_steps")
             return u
+        if op.tile is not None:
+            _hip.check(self.lib.qp_adi_tile_steps(op.tile.handle, _ptr(u), int(nsteps), self.stream), "qp_adi_tile_steps")
+            return u
         for _ in range(int(nsteps)):
             self.adi_step(op, u)
         return u
 
     def adi_step(self, op: DiffusionOperator, u, out=None):
         """Peaceman-Rachford step: (I-rLx)u* = (I+rLy)u + rS; (I-rLy)u' = (I+rLx)u* + rS.  In place unless `out`."""
-        if op.rect is not None:
+        if op.rect is not None or op.tile is not None:
             if out is not None:
                 out.copy_(u)
                 u = out
@@ -365,6 +414,8 @@ class Engine:
                 break
             if op.rect is not None:
                 _hip.check(self.lib.qp_adi_rect_solve(op.rect.handle, _ptr(res), self.stream), "qp_adi_rect_solve")
+            elif op.tile is not None:
+                _hip.check(self.lib.qp_adi_tile_solve(op.tile.handle, _ptr(res), self.stream), "qp_adi_tile_solve")
             else:
                 self.sweep(op, 0, res, res)
                 self.sweep(op, 1, res, res)

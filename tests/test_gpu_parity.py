@@ -615,3 +615,160 @@ def test_collision_kernel_selection():
     assert pick(18, 10.0) == "wave"            # merged bins: not eligible for the register kernel
     assert pick(12, 3.0, nclass=2) == "wave"   # gap classes
     assert pick(65, 10.0) == "generic"
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# tiled path for masked grids (qp_adi_tile.hip)
+# ------------------------------------------------------------------------------------------------------------------
+def _donut(ny, nx, r_out, r_in):
+    y, x = np.indices((ny, nx))
+    rr = np.hypot(y - (ny - 1) / 2.0, x - (nx - 1) / 2.0)
+    return (rr <= r_out) & (rr >= r_in)
+
+
+def _masked_problem(kind, seed):
+    from qpsim_amd.geometry import extract_edge_segments
+    from qpsim_amd.models import BoundaryCondition
+    rng = np.random.default_rng(seed)
+    if kind == "holes":               # random holes everywhere: every tile is general, many short segments
+        ny, nx = 150, 200
+        mask = rng.random((ny, nx)) > 0.12
+    elif kind == "donut":             # clean tiles in the ring, empty ones in the hole and the corners
+        ny, nx = 448, 512
+        mask = _donut(ny, nx, 215.0, 70.0)
+    elif kind == "slab":              # full rectangle with a different BC on half of one side (not a "rect" geometry)
+        ny, nx = 192, 260
+        mask = np.ones((ny, nx), dtype=bool)
+    elif kind == "strip":             # 1 x N strip with a gap
+        ny, nx = 1, 300
+        mask = np.ones((ny, nx), dtype=bool)
+        mask[0, 140:150] = False
+    elif kind == "small":             # smaller than one tile
+        ny, nx = 9, 11
+        mask = rng.random((ny, nx)) > 0.2
+    else:
+        raise ValueError(kind)
+    edges = extract_edge_segments(mask)
+    kinds = [BoundaryCondition("reflective"), BoundaryCondition("dirichlet", 0.4), BoundaryCondition("absorbing"),
+             BoundaryCondition("neumann", -0.05), BoundaryCondition("robin", 0.5, 0.1)]
+    if kind == "slab":
+        bcs = {e.edge_id: kinds[0] for e in edges}
+        # split the left wall: rows < 100 Dirichlet, the rest reflective (edge segments are per wall, so set by cell below)
+        bcs = {e.edge_id: (kinds[1] if e.normal == "left" else kinds[4] if e.normal == "down" else kinds[0]) for e in edges}
+    else:
+        bcs = {e.edge_id: kinds[int(rng.integers(0, 5))] for e in edges}
+    return rng, mask, edges, bcs
+
+
+@pytest.mark.parametrize("kind", ["holes", "donut", "slab", "strip", "small"])
+def test_tile_path_matches_oracle_adi_and_general_kernels(O, kind):
+    """Masked-grid tiled ADI vs the oracle ADI restatement and vs the per-line kernels, 1 and 3 carried steps."""
+    from qpsim_amd.engine import DiffusionOperator, Engine, compile_geometry
+    rng, mask, edges, bcs = _masked_problem(kind, 11)
+    dx, dt = 0.9, 0.11
+    geom = compile_geometry(mask, edges, bcs, dx)
+    if kind == "slab":   # make the geometry non-rect: a second boundary term on part of the left wall
+        geom.ex[:100, 0] *= 0.5
+        geom.sx[:100, 0] *= 0.25
+    eng = Engine(geom)
+    Dc = [6.0, 0.35, 0.0]
+    n = int(mask.sum())
+    u0 = rng.random((len(Dc), n))
+    fast = DiffusionOperator(eng, len(Dc), dt, dcoef=Dc)
+    slow = DiffusionOperator(eng, len(Dc), dt, dcoef=Dc, allow_fast=False)
+    assert fast.rect is None and fast.tile is not None, fast.tile_refused
+    assert slow.tile is None
+    counts = fast.tile.tile_counts
+    py, px = -(-mask.shape[0] // 64), -(-mask.shape[1] // 64)
+    assert sum(counts.values()) == py * px
+    if kind == "donut":
+        assert counts["empty"] > 0 and counts["clean"] > 0 and counts["general"] > 0
+    assert fast.tile.far_coupling < 1e-22
+    for nsteps in (1, 3):
+        a, b = eng.upload_packed(u0), eng.upload_packed(u0)
+        eng.adi_steps(fast, a, nsteps)
+        eng.adi_steps(slow, b, nsteps)
+        ha, hb = eng.download_packed(a), eng.download_packed(b)
+        assert rel_err(ha, hb) < 2e-13, nsteps
+        full = a.detach().cpu().numpy()
+        assert np.all(full[:, ~mask.reshape(-1)] == 0.0)          # holes stay exactly 0
+        if kind != "slab":                                         # the oracle has no per-cell override of BC terms
+            ops = O.build_grid_ops(mask, edges, bcs, dx)
+            for k, D in enumerate(Dc):
+                st = O.ADIStepper(ops, D, dt)
+                want = u0[k].copy()
+                for _ in range(nsteps):
+                    want = st.step(want)
+                assert rel_err(ha[k], want) < 2e-13, (k, nsteps)
+
+
+def test_tile_path_refuses_stiff_steps_and_falls_back(O):
+    """r D = 2.7 keeps 64-cell chunks coupled wherever a line segment spans a whole chunk (ring): the plan is refused and
+    the per-line kernels run; with random holes no segment is that long, so the same step size is accepted."""
+    from qpsim_amd.engine import DiffusionOperator, Engine, compile_geometry
+    for kind, accepted in (("donut", False), ("holes", True)):
+        rng, mask, edges, bcs = _masked_problem(kind, 5)
+        if kind == "donut":
+            mask = mask[:, :256]
+            from qpsim_amd.geometry import extract_edge_segments
+            from qpsim_amd.models import BoundaryCondition
+            edges = extract_edge_segments(mask)
+            bcs = {e.edge_id: BoundaryCondition("absorbing" if i % 2 else "reflective") for i, e in enumerate(edges)}
+        eng = Engine(compile_geometry(mask, edges, bcs, 0.9))
+        op = DiffusionOperator(eng, 1, 0.11, dcoef=[40.0])
+        if accepted:
+            assert op.tile is not None
+        else:
+            assert op.tile is None and "too large" in op.tile_refused
+        u0 = rng.random((1, int(mask.sum())))
+        a = eng.upload_packed(u0)
+        eng.adi_steps(op, a, 1)
+        want = O.ADIStepper(O.build_grid_ops(mask, edges, bcs, 0.9), 40.0, 0.11).step(u0[0])
+        assert rel_err(eng.download_packed(a)[0], want) < 2e-13
+
+
+@pytest.mark.parametrize("kind", ["holes", "donut"])
+def test_exact_cn_iteration_on_the_tile_path_matches_superlu(O, kind):
+    from qpsim_amd.engine import DiffusionOperator, Engine, compile_geometry
+    rng, mask, edges, bcs = _masked_problem(kind, 23)
+    if kind == "donut":
+        mask = mask[96:352, 128:384]          # keep SuperLU quick: centre part of the ring
+        from qpsim_amd.geometry import extract_edge_segments
+        from qpsim_amd.models import BoundaryCondition
+        edges = extract_edge_segments(mask)
+        bcs = {e.edge_id: BoundaryCondition("absorbing" if i % 3 == 0 else "reflective") for i, e in enumerate(edges)}
+    dx, dt = 0.9, 0.11
+    eng = Engine(compile_geometry(mask, edges, bcs, dx))
+    op = DiffusionOperator(eng, 2, dt, dcoef=[6.0, 1.5])
+    assert op.tile is not None
+    u0 = rng.random((2, int(mask.sum())))
+    v = eng.upload_packed(u0)
+    its = eng.cn_exact_step(op, v)
+    ops = O.build_grid_ops(mask, edges, bcs, dx)
+    got = eng.download_packed(v)
+    for k, d in enumerate([6.0, 1.5]):
+        assert rel_err(got[k], O.CNStepper(ops, d, dt).step(u0[k])) < 1e-11
+    assert its < 100
+
+
+def test_tile_path_large_donut_conserves_mass_and_matches_general():
+    """2048^2 ring with reflective walls: mass conservation and agreement with the per-line kernels over 4 steps."""
+    from qpsim_amd.engine import DiffusionOperator, Engine, compile_geometry
+    from qpsim_amd.geometry import extract_edge_segments
+    from qpsim_amd.models import BoundaryCondition
+    N = 2048
+    mask = _donut(N, N, 1000.0, 300.0)
+    edges = extract_edge_segments(mask)
+    bcs = {e.edge_id: BoundaryCondition("reflective") for e in edges}
+    eng = Engine(compile_geometry(mask, edges, bcs, 1.0))
+    n = int(mask.sum())
+    u0 = 1e-4 * (1.0 + np.random.default_rng(0).random((1, n)))
+    fast = DiffusionOperator(eng, 1, 0.1, dcoef=[6.0])
+    slow = DiffusionOperator(eng, 1, 0.1, dcoef=[6.0], allow_fast=False)
+    assert fast.tile is not None
+    a, b = eng.upload_packed(u0), eng.upload_packed(u0)
+    eng.adi_steps(fast, a, 4)
+    eng.adi_steps(slow, b, 4)
+    ha, hb = eng.download_packed(a), eng.download_packed(b)
+    assert rel_err(ha, hb) < 1e-12
+    assert abs(ha.sum() - u0.sum()) / u0.sum() < 1e-12
