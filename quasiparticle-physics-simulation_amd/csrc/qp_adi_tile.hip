@@ -70,6 +70,23 @@ __device__ __forceinline__ void load_codes(const uint16_t* line, unsigned (&cw)[
   }
 }
 
+// Makes every code word "depend" on `x`: decoding them (pure arithmetic, no order of its own inside the unrolled basic
+// block) cannot be hoisted above the point where x is produced.  Without it the decoding of the explicit pass, 3 x 64
+// doubles, is scheduled into the solve that precedes it, where 256 registers are already live.
+__device__ __forceinline__ void codes_after(unsigned (&cw)[TS / 2], double& x) {
+#pragma unroll
+  for (int q = 0; q < TS / 2; ++q) asm volatile("" : "+v"(cw[q]), "+v"(x));
+}
+
+// 1 / x for a pivot (1 <= x, far from overflow): v_rcp_f64 + two Newton steps, 5 dependent instructions instead of the
+// ~12 of the IEEE division sequence; the general kernels are issue-bound and pivots are their inner loop.
+__device__ __forceinline__ double pivot_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(fma(-x, y, 1.0), y, y);
+  y = fma(fma(-x, y, 1.0), y, y);
+  return y;
+}
+
 // (I - a L) x = e along the lane's chunk with neighbour values gl / gr beyond its ends.
 template <int DIR>
 __device__ __forceinline__ void solve_general(double (&e)[TS], const unsigned (&cw)[TS / 2], double a, const double* bct,
@@ -84,7 +101,7 @@ __device__ __forceinline__ void solve_general(double (&e)[TS], const unsigned (&
     const double wp = (code & Bits<DIR>::LP) ? a : 0.0;
     const double bd = a * bct[3 * (code >> kCodeIdxShift) + DIR];
     if (k == TS - 1) e[k] = fma(wp, gr, e[k]);
-    const double inv = 1.0 / fma(-wm, cprev, 1.0 + wm + wp + bd);
+    const double inv = pivot_rcp(fma(-wm, cprev, 1.0 + wm + wp + bd));
     cprev = wp * inv;
     c[k] = cprev;
     dprev = fma(wm, dprev, e[k]) * inv;
@@ -133,7 +150,7 @@ __device__ __forceinline__ void ends_general(const double (&e)[TS], const unsign
       const unsigned code = code_at(cw, k);
       const double wp = (code & Bits<DIR>::LP) ? a : 0.0;
       const double bd = a * bct[3 * (code >> kCodeIdxShift) + DIR];
-      const double inv = 1.0 / fma(-wm, cf, 1.0 + wm + wp + bd);
+      const double inv = pivot_rcp(fma(-wm, cf, 1.0 + wm + wp + bd));
       cf = wp * inv;
       df = fma(wm, df, e[k]) * inv;
       wm = wp;
@@ -143,7 +160,7 @@ __device__ __forceinline__ void ends_general(const double (&e)[TS], const unsign
       const unsigned code = code_at(cw, kb);
       const double wl = (code & Bits<DIR>::LM) ? a : 0.0;
       const double bd = a * bct[3 * (code >> kCodeIdxShift) + DIR];
-      const double inv = 1.0 / fma(-wq, cb, 1.0 + wl + wq + bd);
+      const double inv = pivot_rcp(fma(-wq, cb, 1.0 + wl + wq + bd));
       cb = wl * inv;
       db = fma(wq, db, e[kb]) * inv;
       wq = wl;
@@ -183,7 +200,8 @@ __device__ __forceinline__ TileCoord tile_of(const TileView& v) {
   TileCoord t;
   const int id = blockIdx.x;
   t.b = id % v.nfield;                          // fields of one tile are neighbours in launch order: shared codes hit L2
-  const int packed = v.tiles[GEN ? 1 : 0][id / v.nfield];
+  // the list entry is wave-uniform; say so, or every row address of the tile becomes a per-lane 64-bit value
+  const int packed = __builtin_amdgcn_readfirstlane(v.tiles[GEN ? 1 : 0][id / v.nfield]);
   t.ty = packed >> 16;
   t.tx = packed & 0xffff;
   t.j0 = t.ty * TS;
@@ -219,7 +237,10 @@ __global__ void __launch_bounds__(64) tile_x_kernel(TileView v, double* __restri
     unsigned cw[TS / 2];
     load_codes(v.code_r + (long)(t.j0 + lane) * v.pnx + t.i0, cw);
     solve_general<0>(e, cw, a, bct, gl, gr);
-    if (EXPLICIT) explicit_general<0>(e, cw, a, bct, gl, gr);
+    if (EXPLICIT) {
+      codes_after(cw, e[0]);
+      explicit_general<0>(e, cw, a, bct, gl, gr);
+    }
   } else {
     e[0] = fma(a, gl, e[0]);
     e[TS - 1] = fma(a, gr, e[TS - 1]);
@@ -275,6 +296,7 @@ __global__ void __launch_bounds__(64) tile_y_kernel(TileView v, const double* sr
       unsigned cw[TS / 2];
       load_codes(v.code_c + (long)(t.i0 + lane) * v.pny + t.j0, cw);
       if (MODE != 0) solve_general<1>(e, cw, a, bct, gu, gd);
+      if (MODE == 1) codes_after(cw, e[0]);
       if (MODE != 2) explicit_general<1>(e, cw, a, bct, gu, gd);
     }
   } else {
@@ -313,7 +335,7 @@ __global__ void __launch_bounds__(64) tile_setup_kernel(TileView v, int cls, uns
   {
     const int id = blockIdx.x;
     t.b = id % v.nfield;
-    const int packed = v.tiles[cls][id / v.nfield];
+    const int packed = __builtin_amdgcn_readfirstlane(v.tiles[cls][id / v.nfield]);
     t.ty = packed >> 16;
     t.tx = packed & 0xffff;
     t.j0 = t.ty * TS;
