@@ -14,6 +14,8 @@ Workloads (``--workload``):
   c3                 4096 x 4096, NE=12, recombination + scattering with dynamic phonons (BASELINE configs[2]).
   c4                 64 independent 256 x 256 MKID pixels per GPU, NE=12, full physics (BASELINE configs[3] is 512
                      members over 8 GPUs; members never communicate, so --gpus N runs 64 N members).
+  ring<N>[x<F>]      annulus mask inscribed in N x N (the reference's donut geometry), F fields: masked tiled path;
+                     cell-updates count the cells inside the mask only.
   dd<N>              one N x N scalar field domain-decomposed over the ranks (BASELINE configs[4] = dd8192 at 8 GPUs),
                      neighbour exchange of interface rows over RCCL; "scaling": "strong".
 

@@ -131,6 +131,10 @@ int qp_collision_step(const qp_collision_tables* t, const uint8_t* flags, int64_
                       double* state_out, double* phonon, double* ph_scratch, double dE, double dt,
                       int enable_recombination, int enable_scattering, int update_phonons, void* stream);
 
+/* 1 when qp_collision_step has a register-resident kernel for `ne` energy bins (structured, unshared bin maps and one gap
+ * class are the other conditions); other sizes <= 64 run the one-wave-per-pixel kernel, larger ones the generic kernel. */
+int qp_collision_register_kernel_available(int32_t ne);
+
 /*
  * Explicit fixed-bath collision helpers of the reference's step API (not on its time loop; API parity):
  * rhs = [g_therm - 2 n dE (K_r n)] (if kr) + [dE rho (1-f) (K_s^T n) - n dE ((K_s rho) (1-f))] (if ks), per cell;

@@ -130,6 +130,8 @@ bool collision_fast_dispatch(int ne, const double* kr0, const double* ks0, const
                              const int* anti_bin, const uint8_t* flags, long ncell, const double* sin_, double* sout,
                              double* ph, double dE, double dt, int en_r, int en_s, int upd, hipStream_t stream);
 
+int collision_fast_supported(int ne);
+
 struct WaveCollView {
   int ne, nw, nclass;
   const double* kr0;
@@ -234,3 +236,6 @@ extern "C" int qp_euler_collision(int32_t ne, int64_t ncell, const double* state
                      (int)ne, (long)ncell, state_in, out, kr, g_therm, ks, rho, dE, dt, rhs_only);
   return qp::check_launch("qp_euler_collision");
 }
+
+// 1 when the register-resident collision kernel is instantiated for this number of energy bins
+extern "C" int qp_collision_register_kernel_available(int32_t ne) { return qp::collision_fast_supported(ne); }

@@ -1,192 +1,21 @@
-// Register-resident collision kernel for uniform tables (one gap class) and NE <= 16.
-//
-// On the reference's uniform energy grid the phonon-bin maps have structure: idx_diff[i][j] depends only on |i-j| and
-// idx_sum[i][j] only on i+j (solver.py:668-683 builds them from Ei-Ej and Ei+Ej).  The host verifies this and that no
-// bin is shared between a diagonal and an anti-diagonal (no merged bins), then passes diag_bin[NE] / anti_bin[2NE-1].
-// The pair loops are then walked diagonal by diagonal (scattering) and anti-diagonal by anti-diagonal (recombination):
-// each needs ONE phonon occupation (one coalesced load), accumulates that bin's emission / absorption sums in two
-// registers, and the bin is finalised and stored as soon as its (anti)diagonal is done - no per-cell accumulator planes,
-// no indexed register arrays (everything is unrolled at compile time), tables arrive as scalar loads.
-// K^s_0 and K^r_0 are symmetric, so each unordered pair is visited once.
-#include "qp_common.h"
+// Dispatcher of the register-resident collision kernels (qp_collision_fast.inc) + the instantiations for NE <= 16.
+// Larger NE live in qp_collision_fast_u*.hip; every NE listed in QP_DIAG_NE_LIST has all process combinations.
+#include "qp_collision_fast.inc"
+
+#define QP_DIAG_NE_LIST(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(28) X(30) X(32) X(36) X(40) X(45) X(50)
 
 namespace qp {
 
-typedef const double __attribute__((address_space(4))) * cdtab_t;
-typedef const int __attribute__((address_space(4))) * citab_t;
+QP_DEFINE_DIAG(2) QP_DEFINE_DIAG(3) QP_DEFINE_DIAG(4) QP_DEFINE_DIAG(5) QP_DEFINE_DIAG(6) QP_DEFINE_DIAG(7) QP_DEFINE_DIAG(8) QP_DEFINE_DIAG(9) QP_DEFINE_DIAG(10) QP_DEFINE_DIAG(11) QP_DEFINE_DIAG(12) QP_DEFINE_DIAG(13) QP_DEFINE_DIAG(14) QP_DEFINE_DIAG(15) QP_DEFINE_DIAG(16)
 
-template <typename T>
-__device__ __forceinline__ T uniform_const(const void* p) {
-  const unsigned long long a = (unsigned long long)p;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
-  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-  return (T)(((unsigned long long)hi << 32) | lo);
-}
+QP_DIAG_NE_LIST(QP_DECLARE_DIAG)
 
-// Returns the same wave-uniform pointer, but opaque to the optimiser: the scalar table loads made through it cannot be
-// hoisted above this point.  Without it all NE^2 kernel values are loaded up-front, overflow the ~100 SGPRs and are
-// parked in VGPRs (the register count then grows like 1.4 NE^2 and occupancy drops to one wave per SIMD).
-template <typename T>
-__device__ __forceinline__ T pin_here(T p) {
-  asm volatile("" : "+s"(p));
-  return p;
-}
-
-// Empty asm with the value as in/out operand: the value is "redefined" here, so every instruction that produced it
-// must come before and every consumer after.  Volatile asms keep their relative order (and their order against
-// stores and sched_barrier), which pure VALU instructions do not: without these pins the single huge basic block lets
-// instruction selection sink most accumulator FMAs of every diagonal to the end, with their K*P products kept live.
-template <int N>
-__device__ __forceinline__ void pin_array(double (&a)[N]) {
-#pragma unroll
-  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(a[i]));
-}
-
-struct CollFastView {
-  const double* kr0;      // [NE][NE] or NULL
-  const double* ks0;      // [NE][NE] or NULL
-  const double* rho;      // [NE]
-  const int* diag_bin;    // [NE]      phonon bin of |Ei - Ej| for |i-j| = k
-  const int* anti_bin;    // [2NE-1]   phonon bin of Ei + Ej for i+j = m
-};
-
-__device__ __forceinline__ double relax_update_f(double n, double gain, double loss, double dt) {
-  const double mu = fmax(loss, 0.0);
-  const double P = fmax(gain + (mu - loss) * n, 0.0);
-  const double decay = exp(-mu * dt);
-  const double coeff = (mu < 1e-14) ? dt : (1.0 - decay) / mu;
-  return fmax(decay * n + coeff * P, 0.0);
-}
-
-__device__ __forceinline__ double affine_update_f(double y, double a, double b, double dt) {
-  const double xx = fmin(fmax(b * dt, -80.0), 80.0);
-  const double ex = exp(xx);
-  const double coeff = (fabs(b) < 1e-14) ? dt : (ex - 1.0) / b;
-  return fmax(ex * y + coeff * a, 0.0);
-}
-
-// USE_S / USE_R / UPD are compile-time: with run-time flags the compiler clones and threads the unrolled body into
-// flag-specific paths whose instructions it then interleaves across diagonals (several phonon values live at once).
-template <int NE, bool USE_S, bool USE_R, bool UPD>
-__global__ void __launch_bounds__(128) collision_diag_kernel(CollFastView t, const uint8_t* __restrict__ flags,
-                                                             long ncell, const double* __restrict__ sin_,
-                                                             double* __restrict__ sout, double* __restrict__ ph,
-                                                             double dE, double dt) {
-  // p is kept as a 32-bit offset and every plane base is wave-uniform, so all plane accesses use the
-  // SGPR-base + 32-bit VGPR-offset addressing mode: no 64-bit address registers per plane (host checks ncell < 2^28)
-  const unsigned p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= (unsigned long)ncell) return;
-  if (!(flags[p] & QP_FLAG_ACTIVE)) {
-#pragma unroll
-    for (int i = 0; i < NE; ++i) (sout + (long)i * ncell)[p] = (sin_ + (long)i * ncell)[p];
-    return;
-  }
-  const cdtab_t rho = uniform_const<cdtab_t>(t.rho);
-  const cdtab_t ks = uniform_const<cdtab_t>(t.ks0);
-  const cdtab_t kr = uniform_const<cdtab_t>(t.kr0);
-  const citab_t dbin = uniform_const<citab_t>(t.diag_bin);
-  const citab_t abin = uniform_const<citab_t>(t.anti_bin);
-  constexpr bool use_s = USE_S, use_r = USE_R, upd_ph = UPD;
-
-  double n[NE], q[NE], ga[NE], la[NE];
-#pragma unroll
-  for (int i = 0; i < NE; ++i) {
-    n[i] = (sin_ + (long)i * ncell)[p];
-    const double r = rho[i];
-    q[i] = r * fmax(1.0 - n[i] / fmax(r, 1e-30), 0.0);
-    ga[i] = 0.0;
-    la[i] = 0.0;
-  }
-
-  // One phonon occupation per (anti)diagonal; the next one is prefetched while the current one is processed.  The
-  // scheduling barriers keep the compiler from hoisting every load / exp chain to the top (which costs ~60 live
-  // doubles and halves the occupancy); with them the live set is n, q, ga, la plus one diagonal's temporaries.
-  if (use_s) {
-    double Pnext = NE > 1 ? (ph + (long)dbin[1] * ncell)[p] : 0.0;
-#pragma unroll
-    for (int k = 1; k < NE; ++k) {
-      double* pw = ph + (long)dbin[k] * ncell;
-      const cdtab_t ksk = pin_here(ks);
-      const double P = Pnext;
-      if (k + 1 < NE) Pnext = (ph + (long)dbin[k + 1] * ncell)[p];
-      double em = 0.0, ab = 0.0;
-#pragma unroll
-      for (int j = 0; j + k < NE; ++j) {
-        const int i = j + k;                    // E_i > E_j: (i -> j) emits, (j -> i) absorbs
-        const double K = ksk[i * NE + j];
-        const double t1 = K * P, t2 = K + t1;   // K P and K (1 + P)
-        ga[i] = fma(t1, n[j], ga[i]);
-        la[i] = fma(t2, q[j], la[i]);
-        ga[j] = fma(t2, n[i], ga[j]);
-        la[j] = fma(t1, q[i], la[j]);
-        em = fma(n[i] * K, q[j], em);
-        ab = fma(n[j] * K, q[i], ab);
-      }
-      if (upd_ph) pw[p] = affine_update_f(P, dE * em, dE * (em - ab), dt);
-      pin_array(ga);
-      pin_array(la);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  if (use_r) {
-    double Pnext = (ph + (long)abin[0] * ncell)[p];
-#pragma unroll
-    for (int m = 0; m < 2 * NE - 1; ++m) {
-      double* pw = ph + (long)abin[m] * ncell;
-      const cdtab_t krm = pin_here(kr);
-      const double P = Pnext;
-      if (m + 1 < 2 * NE - 1) Pnext = (ph + (long)abin[m + 1] * ncell)[p];
-      double rec = 0.0, pb = 0.0;
-#pragma unroll
-      for (int i = 0; i < NE; ++i) {
-        const int j = m - i;
-        if (j < 0 || j >= NE || j > i) continue;
-        const double K2 = 2.0 * krm[i * NE + j];
-        const double t1 = K2 * P, t2 = K2 + t1;
-        if (i != j) {
-          la[i] = fma(t2, n[j], la[i]);
-          la[j] = fma(t2, n[i], la[j]);
-          ga[i] = fma(t1, q[j], ga[i]);
-          ga[j] = fma(t1, q[i], ga[j]);
-          rec = fma(n[i] * K2, n[j], rec);
-          pb = fma(q[i] * K2, q[j], pb);
-        } else {
-          la[i] = fma(t2, n[i], la[i]);
-          ga[i] = fma(t1, q[i], ga[i]);
-          rec = fma(0.5 * K2 * n[i], n[i], rec);
-          pb = fma(0.5 * K2 * q[i], q[i], pb);
-        }
-      }
-      if (upd_ph) pw[p] = affine_update_f(P, dE * rec, dE * (rec - pb), dt);
-      pin_array(ga);
-      pin_array(la);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < NE; ++i) {
-    (sout + (long)i * ncell)[p] = relax_update_f(n[i], dE * q[i] * ga[i], dE * la[i], dt);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-template <int NE, bool S, bool R, bool U>
-static void launch_one(const CollFastView& v, const uint8_t* flags, long ncell, const double* sin_, double* sout,
-                       double* ph, double dE, double dt, hipStream_t stream) {
-  const unsigned blocks = (unsigned)((ncell + 127) / 128);
-  hipLaunchKernelGGL((collision_diag_kernel<NE, S, R, U>), dim3(blocks), dim3(128), 0, stream, v, flags, ncell, sin_,
-                     sout, ph, dE, dt);
-}
-
-template <int NE>
-static void launch_diag(const CollFastView& v, const uint8_t* flags, long ncell, const double* sin_, double* sout,
-                        double* ph, double dE, double dt, bool s, bool r, bool u, hipStream_t stream) {
-#define QP_GO(S, R, U) launch_one<NE, S, R, U>(v, flags, ncell, sin_, sout, ph, dE, dt, stream)
-  if (s && r) { if (u) QP_GO(true, true, true); else QP_GO(true, true, false); }
-  else if (s) { if (u) QP_GO(true, false, true); else QP_GO(true, false, false); }
-  else if (r) { if (u) QP_GO(false, true, true); else QP_GO(false, true, false); }
-  else QP_GO(false, false, false);
-#undef QP_GO
+__global__ void __launch_bounds__(256) collision_none_kernel(const uint8_t* __restrict__ flags, long ncell, long total,
+                                                             const double* __restrict__ sin_, double* __restrict__ sout) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const double v = sin_[t];
+  sout[t] = (flags[t % ncell] & QP_FLAG_ACTIVE) ? fmax(v, 0.0) : v;
 }
 
 // returns false when NE has no instantiation or the cell count exceeds the 32-bit offset range
@@ -196,12 +25,30 @@ bool collision_fast_dispatch(int ne, const double* kr0, const double* ks0, const
   if (ncell >= (1L << 28)) return false;
   CollFastView v{kr0, ks0, rho, diag_bin, anti_bin};
   const bool s = en_s && ks0, r = en_r && kr0, u = upd && (s || r);
+  diag_launcher_t fn = nullptr;
   switch (ne) {
-#define QP_CASE(N) case N: launch_diag<N>(v, flags, ncell, sin_, sout, ph, dE, dt, s, r, u, stream); return true;
-    QP_CASE(2) QP_CASE(3) QP_CASE(4) QP_CASE(5) QP_CASE(6) QP_CASE(7) QP_CASE(8) QP_CASE(9) QP_CASE(10) QP_CASE(11)
-    QP_CASE(12) QP_CASE(13) QP_CASE(14) QP_CASE(15) QP_CASE(16)
+#define QP_CASE(N) case N: fn = (s && r) ? diag_launcher_##N##_11 : r ? diag_launcher_##N##_01 : diag_launcher_##N##_10; break;
+    QP_DIAG_NE_LIST(QP_CASE)
 #undef QP_CASE
     default: return false;
+  }
+  if (!s && !r) {   // no process enabled: relaxation with zero gain and loss, n' = max(n, 0) on active cells
+    const long total = ncell * ne;
+    hipLaunchKernelGGL(collision_none_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, flags, ncell,
+                       total, sin_, sout);
+    return true;
+  }
+  fn(v, flags, ncell, sin_, sout, ph, dE, dt, u, stream);
+  return true;
+}
+
+// list of NE with a register kernel (for the host-side choice / tests)
+int collision_fast_supported(int ne) {
+  switch (ne) {
+#define QP_CASE(N) case N: return 1;
+    QP_DIAG_NE_LIST(QP_CASE)
+#undef QP_CASE
+    default: return 0;
   }
 }
 

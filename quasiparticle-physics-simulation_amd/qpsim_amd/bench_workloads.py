@@ -26,24 +26,42 @@ def _rect_engine(N: int, device):
     return Engine(compile_geometry(mask, edges, bcs, 1.0), device=device)
 
 
+def ring_mask(N: int) -> np.ndarray:
+    """Annulus inscribed in the N x N grid (outer radius ~N/2, inner radius 0.15 N): the reference's "donut" test
+    geometry (qpsim/test_cases.py:627-780) at benchmark size."""
+    y, x = np.indices((N, N))
+    rr = np.hypot(y - (N - 1) / 2.0, x - (N - 1) / 2.0)
+    return (rr <= 0.498 * N) & (rr >= 0.15 * N)
+
+
 class ADIWorkload:
     """N x N scalar CN-ADI diffusion; `chunk` consecutive steps per library call share the carried state."""
 
-    def __init__(self, N: int, device, nfield: int = 1):
+    def __init__(self, N: int, device, nfield: int = 1, ring: bool = False):
         self.N, self.nfield = N, nfield
-        self.eng = _rect_engine(N, device)
+        if ring:
+            mask = ring_mask(N)
+            edges = extract_edge_segments(mask)
+            bcs = {e.edge_id: BoundaryCondition("reflective") for e in edges}
+            self.eng = Engine(compile_geometry(mask, edges, bcs, 1.0), device=device)
+            ncell = int(mask.sum())
+        else:
+            self.eng = _rect_engine(N, device)
+            ncell = N * N
         torch = self.eng.torch
         rng = np.random.default_rng(0)
-        init = 1e-4 * (1.0 + rng.random((nfield, N * N)))
-        self.u = torch.as_tensor(init, device=self.eng.device)
+        init = 1e-4 * (1.0 + rng.random((nfield, ncell)))
+        self.u = self.eng.upload_packed(init) if ring else torch.as_tensor(init, device=self.eng.device)
         D = [6.0] * nfield
         self.op = DiffusionOperator(self.eng, nfield, 0.1, dcoef=D)
         self.grid = [N, N]
-        self.cell_updates_per_step = float(N) * N * nfield
+        self.cell_updates_per_step = float(ncell) * nfield          # cells inside the mask only
         self.bytes_per_step = 32.0 * self.cell_updates_per_step     # 2 sweeps x (8 B read + 8 B write)
-        self.path = "rect-tiled partition ADI" if self.op.rect is not None else "general per-line Thomas"
+        self.path = ("rect-tiled partition ADI" if self.op.rect is not None else
+                     f"masked tiled ADI {self.op.tile.tile_counts}" if self.op.tile is not None else "general per-line Thomas")
+        shape = "ring mask (donut)" if ring else "full rectangle"
         self.description = (f"{N}x{N} fp64 CN-ADI step (Peaceman-Rachford, both sweeps), {nfield} field(s), "
-                            "full rectangle, reflective walls, D=6 dt=0.1 dx=1")
+                            f"{shape}, reflective walls, D=6 dt=0.1 dx=1")
         self._pending = 0
 
     def run(self, k: int):
@@ -83,7 +101,9 @@ class ADIWorkload:
         achieved = bytes_per_launch / per_sweep_s / 1e9
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": self._pmc_traffic(),
-                "kernel": "rect_x_kernel / rect_y_kernel (one tile sweep)" if self.op.rect is not None else "thomas_lines_kernel",
+                "kernel": ("rect_x_kernel / rect_y_kernel (one tile sweep)" if self.op.rect is not None else
+                           "tile_x_kernel / tile_y_kernel, clean + general launches of one sweep" if self.op.tile is not None
+                           else "thomas_lines_kernel"),
                 "bytes_per_launch": bytes_per_launch, "avg_launch_us": per_sweep_s * 1e6,
                 "note": "launch time = (event time of k-step calls) / (2k+1 sweep launches); includes the reduced-system kernels"}
 
@@ -259,6 +279,9 @@ def build(name: str, device):
     m = re.fullmatch(r"adi(\d+)", name)
     if m:
         return ADIWorkload(int(m.group(1)), device)
+    m = re.fullmatch(r"ring(\d+)(?:x(\d+))?", name)
+    if m:   # ring<N>[x<F>]: annulus mask inside N x N (masked tiled path), F fields
+        return ADIWorkload(int(m.group(1)), device, nfield=int(m.group(2) or 1), ring=True)
     m = re.fullmatch(r"adi(\d+)x(\d+)", name)
     if m:   # adi<N>x<F>: F independent fields of N x N (ensemble batch)
         return ADIWorkload(int(m.group(1)), device, nfield=int(m.group(2)))

@@ -462,7 +462,7 @@ class Engine:
         wave_ok = ne <= 64 and nw <= 192
         h["kernel"] = ("generic" if (kernel == "generic" or not wave_ok) else
                        "register" if (kernel == "auto" and structure is not None and not shared and nclass == 1
-                                      and 2 <= ne <= 16) else "wave")
+                                      and bool(self.lib.qp_collision_register_kernel_available(ne))) else "wave")
         h["fast"] = h["kernel"] != "generic"      # no accumulator planes needed
         h["struct"] = _hip.CollisionTables(ne, nw, nclass, _ptr(h["kr0"]), _ptr(h["ks0"]), _ptr(h["rho"]),
                                            _ptr(h["idx_diff"]), _ptr(h["idx_sum"]), _ptr(h["sign"]), _ptr(h["cls"]),

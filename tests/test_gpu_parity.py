@@ -423,10 +423,12 @@ def test_rect_fast_path_large_reflective_conserves_mass_and_matches_general():
     assert ha.min() >= u0.min() and ha.max() <= u0.max()         # discrete maximum principle for r D = 0.3
 
 
-@pytest.mark.parametrize("ne,fmax", [(2, 3.0), (5, 3.0), (8, 4.0), (12, 3.0), (16, 10.0)])
+@pytest.mark.parametrize("ne,fmax", [(2, 3.0), (5, 3.0), (8, 4.0), (12, 3.0), (16, 10.0), (20, 3.0), (32, 3.0), (40, 3.0),
+                                     (50, 10.0)])
 @pytest.mark.parametrize("en_r,en_s,upd", [(True, True, True), (True, False, True), (False, True, True), (True, True, False)])
 def test_fast_collision_kernel_matches_generic_and_oracle(O, ne, fmax, en_r, en_s, upd):
-    """Register-resident diagonal kernel (uniform tables, NE <= 16) vs the generic kernel and the oracle."""
+    """Register-resident diagonal kernel (uniform tables; NE = 50, the reference default, runs the split
+    quasiparticle / phonon pair with q re-formed on the fly) vs the generic kernel and the oracle."""
     from qpsim_amd import tables as T
     from qpsim_amd.engine import CompiledGeometry, Engine, link_flags, structured_bin_maps
     rng = np.random.default_rng(ne * 7 + int(en_r) + 2 * int(en_s))
@@ -445,19 +447,22 @@ def test_fast_collision_kernel_matches_generic_and_oracle(O, ne, fmax, en_r, en_
     outs = []
     for fast in (True, False):
         tab = eng.make_collision_tables(kr[None], ks[None], rho[None], idx_d, idx_s, sg, allow_fast=fast)
-        assert tab["fast"] == fast
+        assert tab["fast"] == fast and tab["kernel"] == ("register" if fast else "generic")
         s_in, p_dev = eng.upload_packed(state), eng.upload_packed(ph)
         s_out = eng.empty(ne, eng.ncell)
         eng.collide(tab, s_in, s_out, p_dev, dE, 0.37, en_r, en_s, upd)
         outs.append((eng.download_packed(s_out), eng.download_packed(p_dev), s_out.cpu().numpy()))
-    assert rel_err(outs[0][0], outs[1][0]) < 1e-12 and rel_err(outs[0][1], outs[1][1]) < 1e-11
+    # phonon planes: (e^{b dt} - 1)/b without expm1 (solver.py:697) amplifies summation-order differences in b by
+    # eps/|b dt|; with 50 bins and occupations up to 0.95 every kernel (and the oracle) sits within PHONON_TOL of the others
+    ptol = 1e-11 if ne <= 16 else PHONON_TOL
+    assert rel_err(outs[0][0], outs[1][0]) < 1e-12 and rel_err(outs[0][1], outs[1][1]) < ptol
     assert np.all(outs[0][2][:, ~mask.reshape(-1)] == 0.0)
     tables = {"rho": rho[None], "Kr0": kr[None] if en_r else None, "Ks0": ks[None] if en_s else None,
               "cls": np.zeros(n, dtype=int), "idx_diff": idx_d, "idx_sum": idx_s, "sign": sg, "dE": dE}
     s_ref, p_ref = state.copy(), ph.copy()
     O.collision_step(s_ref, p_ref, tables, 0.37, en_r=en_r, en_s=en_s, update_phonons=upd)
     # vs the host oracle the exp() last-bit caveat of solver.py:661,697 applies (see the golden-vector test above)
-    assert rel_err(outs[0][0], s_ref) < 2e-11 and rel_err(outs[0][1], p_ref) < 2e-11
+    assert rel_err(outs[0][0], s_ref) < 2e-11 and rel_err(outs[0][1], p_ref) < (2e-11 if ne <= 16 else PHONON_TOL)
 
 
 def test_merged_phonon_bins_fall_back_to_generic_kernel():
@@ -611,7 +616,8 @@ def test_collision_kernel_selection():
         return eng.make_collision_tables(k, k, rho, idd, ids, sg, np.zeros(8, dtype=int) if nclass > 1 else None)["kernel"]
 
     assert pick(12, 3.0) == "register" and pick(16, 10.0) == "register"
-    assert pick(17, 3.0) == "wave" and pick(50, 10.0) == "wave" and pick(64, 10.0) == "wave"
+    assert pick(24, 3.0) == "register" and pick(50, 10.0) == "register"      # instantiated sizes incl. the reference default
+    assert pick(17, 3.0) == "wave" and pick(33, 10.0) == "wave" and pick(64, 10.0) == "wave"
     assert pick(18, 10.0) == "wave"            # merged bins: not eligible for the register kernel
     assert pick(12, 3.0, nclass=2) == "wave"   # gap classes
     assert pick(65, 10.0) == "generic"
