@@ -171,7 +171,7 @@ def main():
     if hasattr(wl, "coll_bytes_per_call"):
         result["pixel_steps_per_s"] = wl.npix * world * args.steps / elapsed
     if rank == 0:
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0 would hold the others up)
             result["cpu_baseline"] = cpu_baseline(args, args.workload)
         print(json.dumps(result))
     if use_dist:

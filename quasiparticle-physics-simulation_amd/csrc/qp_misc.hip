@@ -75,19 +75,22 @@ __global__ void __launch_bounds__(256) pauli_partial_kernel(const double* __rest
   // np.argmax returns the first maximum in C order, so ties resolve to the smallest linear index.
   double f = -1.0;
   long fi = 0x7fffffffffffffffL, forb = -1;
-  const long total = ncell * ne;
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-    const long p = t % ncell;
-    if (!(flags[p] & QP_FLAG_ACTIVE)) continue;
-    const int i = (int)(t / ncell);
-    const double r = rho[(long)(cls ? cls[p] : 0) * ne + i];
-    const double n = s[t];
-    double occ = 0.0;
-    if (r > 1e-30) occ = n / fmax(r, 1e-30);
-    else if (n > floor_ && (forb < 0 || t < forb)) forb = t;
-    if (occ > f || (occ == f && t < fi)) { f = occ; fi = t; }
+  // blockIdx.y strides over energy bins, blockIdx.x over cells: no 64-bit div / mod per element
+  for (int i = blockIdx.y; i < ne; i += gridDim.y) {
+    const double* si = s + (long)i * ncell;
+    const double r0 = rho[i];
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < ncell; p += (long)gridDim.x * blockDim.x) {
+      if (!(flags[p] & QP_FLAG_ACTIVE)) continue;
+      const double r = cls ? rho[(long)cls[p] * ne + i] : r0;
+      const double n = si[p];
+      const long t = (long)i * ncell + p;
+      double occ = 0.0;
+      if (r > 1e-30) occ = n / fmax(r, 1e-30);
+      else if (n > floor_ && (forb < 0 || t < forb)) forb = t;
+      if (occ > f || (occ == f && t < fi)) { f = occ; fi = t; }
+    }
   }
-  pauli_block_reduce(f, fi, forb, part + blockIdx.x);
+  pauli_block_reduce(f, fi, forb, part + (long)blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 __global__ void __launch_bounds__(256) pauli_final_kernel(const PauliPartial* part, int nparts, double* out_vals,
@@ -168,11 +171,14 @@ int qp_pauli_stats(const double* state, const double* rho, const int32_t* cls, c
   QP_REQUIRE(state && rho && flags && workspace && out_vals && out_idx, "NULL argument");
   QP_REQUIRE(ne > 0 && nclass > 0 && ncell > 0, "ne, nclass, ncell must be positive");
   QP_REQUIRE(nclass == 1 || cls, "cls is required when nclass > 1");
-  long blocks = (ncell * ne + 255) / 256;
-  if (blocks > qp::kRedBlocks) blocks = qp::kRedBlocks;
+  const long by = ne < qp::kRedBlocks ? ne : qp::kRedBlocks;
+  long bx = (ncell + 255) / 256;
+  if (bx > qp::kRedBlocks / by) bx = qp::kRedBlocks / by;
+  if (bx < 1) bx = 1;
+  const long blocks = bx * by;
   auto* part = (qp::PauliPartial*)workspace;
-  hipLaunchKernelGGL(qp::pauli_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, state, rho,
-                     cls, flags, (int)ne, (long)ncell, density_floor, part);
+  hipLaunchKernelGGL(qp::pauli_partial_kernel, dim3((unsigned)bx, (unsigned)by), dim3(256), 0, (hipStream_t)stream, state,
+                     rho, cls, flags, (int)ne, (long)ncell, density_floor, part);
   hipLaunchKernelGGL(qp::pauli_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, (int)blocks, out_vals,
                      (long*)out_idx);
   return qp::check_launch("qp_pauli_stats");

@@ -116,7 +116,7 @@ class CoupledWorkload:
     """
 
     def __init__(self, N, device, *, ne=12, recombination=True, scattering=True, dynamic_phonons=True, label="",
-                 members=1):
+                 members=1, fmax=3.0):
         """``members`` independent N x N problems are batched: planes are laid out [bin][member][cell], so the ADI plan
         sees NE*members fields of N x N and the collision kernel sees members*N*N pixels (no coupling between members)."""
         self.N, self.nfield, self.ne, self.members = N, ne * members, ne, members
@@ -124,7 +124,7 @@ class CoupledWorkload:
         torch = eng.torch
         gap, D0, dt = 180.0, 6.0, 0.1
         self.dt = dt
-        E, dE = T.build_energy_grid(gap, 1.0, 3.0, ne)
+        E, dE = T.build_energy_grid(gap, 1.0, fmax, ne)
         self.dE = dE
         om, idx_d, idx_s, sg = T.build_phonon_frequency_map(E)
         self.nw = om.size
@@ -150,7 +150,7 @@ class CoupledWorkload:
         planes_rw = (ne + self.nw) + (ne + (self.nw if dynamic_phonons else 0))
         self.coll_bytes_per_call = 8.0 * planes_rw * npix
         self.bytes_per_step = 48.0 * self.cell_updates_per_step + 2 * self.coll_bytes_per_call
-        self.path = ("rect-tiled ADI + " + ("diagonal register collision kernel" if self.tab["fast"] else "generic collision kernel"))
+        self.path = f"rect-tiled ADI + {self.tab['kernel']} collision kernel"
         ens = f"{members} independent members of " if members > 1 else ""
         self.description = (f"{label}{ens}{N}x{N} fp64, NE={ne}, Nw={self.nw}: Strang C(dt/2) D(dt) C(dt/2) + Pauli guard per step; "
                             f"recombination={'on' if recombination else 'off'}, scattering={'on' if scattering else 'off'}, "
@@ -210,7 +210,8 @@ class CoupledWorkload:
         achieved = self.coll_bytes_per_call / per_call / 1e9
         pairs = self.ne * self.ne
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "kernel": "collision_diag_kernel" if self.tab["fast"] else "collision_generic_kernel",
+                "traffic": None, "kernel": {"register": "collision_diag_kernel", "wave": "collision_wave_kernel",
+                                            "generic": "collision_generic_kernel"}[self.tab["kernel"]],
                 "bytes_per_launch": self.coll_bytes_per_call, "avg_launch_us": per_call * 1e6,
                 "pixel_updates_per_s": self.npix / per_call,
                 "note": f"16*(NE+Nw) B per pixel when phonons are dynamic; ~26*NE^2 = {26 * pairs} flop per pixel-update"}
@@ -294,7 +295,8 @@ def build(name: str, device):
     if name == "c3":
         return CoupledWorkload(4096, device, recombination=True, scattering=True, dynamic_phonons=True,
                                label="BASELINE configs[2]: ")
-    m = re.fullmatch(r"coupled(\d+)", name)
-    if m:
-        return CoupledWorkload(int(m.group(1)), device)
+    m = re.fullmatch(r"coupled(\d+)(?:ne(\d+))?", name)
+    if m:   # coupled<N>[ne<NE>]: full physics on N x N with NE energy bins (ne50 = the reference's default resolution)
+        ne = int(m.group(2) or 12)
+        return CoupledWorkload(int(m.group(1)), device, ne=ne, fmax=3.0 if ne <= 24 else 10.0)
     raise ValueError(f"unknown workload '{name}'")
