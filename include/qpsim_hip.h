@@ -234,7 +234,8 @@ int qp_adi_rect_iface_halo(qp_adi_rect_plan* plan, int32_t dir, int32_t side, in
 int qp_adi_rect_set_field_halo(qp_adi_rect_plan* plan, int32_t side, const double* rows, void* stream);
 
 /*
- * Tiled CN-ADI path for MASKED grids: any mask, any per-face boundary condition, one diffusivity per field.
+ * Tiled CN-ADI path for MASKED grids: any mask, any per-face boundary condition, one diffusivity per field
+ * (qp_adi_tile_plan_create) or a diffusivity field per energy bin (qp_adi_tile_plan_create_var).
  * Replaces the same reference loop as the rectangle path (solver.py:1443-1452 / :1545-1555) on the geometries the
  * reference actually ships (strips with holes, donuts, GDS shapes: build_laplacian_with_boundaries solver.py:152-212).
  *   flags, ex, ey, sx, sy   HOST arrays [ny*nx] with the meaning of qp_grid_desc (the plan compresses them into 16-bit
@@ -251,6 +252,12 @@ typedef struct qp_adi_tile_plan qp_adi_tile_plan;
 int qp_adi_tile_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, const double* dcoef_host,
                             const uint8_t* flags, const double* ex, const double* ey, const double* sx, const double* sy,
                             qp_adi_tile_plan** out);
+/* Same for spatially varying diffusivity (build_variable_diffusion_laplacian, solver.py:235-321: harmonic-mean face values,
+ * boundary terms scaled by the cell's D): dfield is a DEVICE array [nfield][ny*nx] read once at plan creation (face weights
+ * and r*D are stored per field in the layouts the sweeps read: 4 planes per field).  Every non-empty tile is "general". */
+int qp_adi_tile_plan_create_var(int32_t ny, int32_t nx, int32_t nfield, double r, const double* dfield,
+                                const uint8_t* flags, const double* ex, const double* ey, const double* sx,
+                                const double* sy, qp_adi_tile_plan** out);
 int qp_adi_tile_plan_destroy(qp_adi_tile_plan* plan);
 int qp_adi_tile_plan_info(const qp_adi_tile_plan* plan, int32_t* counts, double* far);
 int qp_adi_tile_steps(qp_adi_tile_plan* plan, double* u, int32_t nsteps, void* stream);

@@ -47,8 +47,14 @@ struct TileView {
   int nbc;
   double* iface[2];             // per dir [nfield][2P+2][nlines]: row 2p+1 = y_p[first], row 2p+2 = y_p[last]
   double* coef[2];              // same shape: row 2p+1 = t_p, row 2p+2 = s_p
-  const int32_t* tiles[2];      // [0] clean, [1] general: (ty << 16) | tx
+  const int32_t* tiles[2];      // [0] clean, [1] general: (has_bc << 30) | (ty << 16) | tx
   int ntiles[2];
+  // variable-D plans (var != 0): per field, padded [pny][pnx] row-major (x) and [pnx][pny] column-major (y)
+  int var;
+  const double* wx;             // weight of the face between (j, i) and (j, i+1)
+  const double* wy;             // weight of the face between (j, i) and (j+1, i)
+  const double* rdx;            // r D of the cell, row-major
+  const double* rdy;            // r D of the cell, column-major
 };
 
 template <int DIR> struct Bits {
@@ -87,19 +93,70 @@ __device__ __forceinline__ double pivot_rcp(double x) {
   return y;
 }
 
-// (I - a L) x = e along the lane's chunk with neighbour values gl / gr beyond its ends.
+// Per-cell coefficients of the lane's line, uniform diffusivity: decoded from the codes.
+//   wm(k) / wp(k)  weights of the faces towards k-1 / k+1 (0 without a link)      bd(k)  boundary diagonal term
+//   src(k)         boundary source of both directions
 template <int DIR>
-__device__ __forceinline__ void solve_general(double (&e)[TS], const unsigned (&cw)[TS / 2], double a, const double* bct,
-                                              double gl, double gr) {
+struct UniCoef {
+  const unsigned (&cw)[TS / 2];
+  double a;
+  const double* bct;
+  __device__ __forceinline__ double wm(int k) const { return (code_at(cw, k) & Bits<DIR>::LM) ? a : 0.0; }
+  __device__ __forceinline__ double wp(int k) const { return (code_at(cw, k) & Bits<DIR>::LP) ? a : 0.0; }
+  __device__ __forceinline__ double bd(int k) const { return a * bct[3 * (code_at(cw, k) >> kCodeIdxShift) + DIR]; }
+  __device__ __forceinline__ double src(int k) const { return a * bct[3 * (code_at(cw, k) >> kCodeIdxShift) + 2]; }
+  __device__ __forceinline__ void tie(double&) const {}
+};
+
+// Spatially varying diffusivity: face weights r * harmonic mean come from a per-field plane (w[k] = face k | k+1 of the
+// lane's line, wfirst = face towards the previous chunk).  Tiles without boundary faces (almost all) hold the line's
+// weights in registers.
+template <int DIR>
+struct VarCoef {
+  const double (&w)[TS];
+  double wfirst;
+  __device__ __forceinline__ double wm(int k) const { return k > 0 ? w[k - 1] : wfirst; }
+  __device__ __forceinline__ double wp(int k) const { return w[k]; }
+  __device__ __forceinline__ double bd(int) const { return 0.0; }
+  __device__ __forceinline__ double src(int) const { return 0.0; }
+  __device__ __forceinline__ void tie(double&) const {}
+};
+
+// Variable-D tiles WITH boundary faces: boundary terms scale with r D of the cell (solver.py:296-311), so the cell's r D is
+// needed next to its weights.  Holding both lines in registers does not fit beside e and c; these (rare) tiles stream
+// weights and r D from the lane's contiguous lines cell by cell instead.  `zero` is an opaque 0 added to every index and
+// re-defined together with the recurrence value at each cell, which keeps the loads of later cells from being hoisted.
+template <int DIR>
+struct StreamCoef {
+  const double* wl;
+  const double* rd;
+  const unsigned (&cw)[TS / 2];
+  const double* bct;
+  double wfirst;
+  mutable unsigned zero;
+  __device__ __forceinline__ double wm(int k) const { return k > 0 ? wl[k - 1 + zero] : wfirst; }
+  __device__ __forceinline__ double wp(int k) const { return wl[k + zero]; }
+  __device__ __forceinline__ double bd(int k) const {
+    return rd[k + zero] * bct[3 * (code_at(cw, k) >> kCodeIdxShift) + DIR];
+  }
+  __device__ __forceinline__ double src(int k) const {
+    return rd[k + zero] * bct[3 * (code_at(cw, k) >> kCodeIdxShift) + 2];
+  }
+  __device__ __forceinline__ void tie(double& chain) const { asm volatile("" : "+v"(zero), "+v"(chain)); }
+};
+
+// (I - L_w) x = e along the lane's chunk with neighbour values gl / gr beyond its ends.
+template <class Coef>
+__device__ __forceinline__ void solve_general(double (&e)[TS], const Coef& co, double gl, double gr) {
   double c[TS];
-  double wm = (code_at(cw, 0) & Bits<DIR>::LM) ? a : 0.0;
+  double wm = co.wm(0);
   e[0] = fma(wm, gl, e[0]);
   double cprev = 0.0, dprev = 0.0;
 #pragma unroll
   for (int k = 0; k < TS; ++k) {
-    const unsigned code = code_at(cw, k);
-    const double wp = (code & Bits<DIR>::LP) ? a : 0.0;
-    const double bd = a * bct[3 * (code >> kCodeIdxShift) + DIR];
+    co.tie(cprev);
+    const double wp = co.wp(k);
+    const double bd = co.bd(k);
     if (k == TS - 1) e[k] = fma(wp, gr, e[k]);
     const double inv = pivot_rcp(fma(-wm, cprev, 1.0 + wm + wp + bd));
     cprev = wp * inv;
@@ -116,18 +173,16 @@ __device__ __forceinline__ void solve_general(double (&e)[TS], const unsigned (&
   }
 }
 
-// e <- (I + a L) e + a (sx + sy) along the lane's chunk
-template <int DIR>
-__device__ __forceinline__ void explicit_general(double (&e)[TS], const unsigned (&cw)[TS / 2], double a, const double* bct,
-                                                 double gl, double gr) {
+// e <- (I + L_w) e + boundary sources along the lane's chunk
+template <class Coef>
+__device__ __forceinline__ void explicit_general(double (&e)[TS], const Coef& co, double gl, double gr) {
   double prev = gl;
-  double wm = (code_at(cw, 0) & Bits<DIR>::LM) ? a : 0.0;
+  double wm = co.wm(0);
 #pragma unroll
   for (int k = 0; k < TS; ++k) {
-    const unsigned code = code_at(cw, k);
-    const double wp = (code & Bits<DIR>::LP) ? a : 0.0;
-    const unsigned idx = code >> kCodeIdxShift;
-    const double bd = a * bct[3 * idx + DIR], src = a * bct[3 * idx + 2];
+    co.tie(prev);
+    const double wp = co.wp(k);
+    const double bd = co.bd(k), src = co.src(k);
     const double cur = e[k];
     const double nxt = (k + 1 < TS) ? e[k + 1] : gr;
     e[k] = fma(wm, prev - cur, fma(wp, nxt - cur, fma(-bd, cur, cur + src)));
@@ -138,29 +193,26 @@ __device__ __forceinline__ void explicit_general(double (&e)[TS], const unsigned
 
 // First and last entry of A_p^-1 e (chunk-local system, couplings to the neighbouring chunks dropped), plus the
 // interface coefficients s = wp_last h[last], t = wm_first g[first] (by-products of the two eliminations).
-template <int DIR>
-__device__ __forceinline__ void ends_general(const double (&e)[TS], const unsigned (&cw)[TS / 2], double a, const double* bct,
-                                             double& yf, double& yl, double& s, double& t) {
-  double wm = (code_at(cw, 0) & Bits<DIR>::LM) ? a : 0.0;
-  double wq = (code_at(cw, TS - 1) & Bits<DIR>::LP) ? a : 0.0;
+template <class Coef>
+__device__ __forceinline__ void ends_general(const double (&e)[TS], const Coef& co, double& yf, double& yl, double& s,
+                                             double& t) {
+  double wm = co.wm(0);
+  double wq = co.wp(TS - 1);
   double cf = 0.0, df = 0.0, cb = 0.0, db = 0.0;
 #pragma unroll
   for (int k = 0; k < TS; ++k) {
+    co.tie(cf);
     {  // forward elimination, cell k
-      const unsigned code = code_at(cw, k);
-      const double wp = (code & Bits<DIR>::LP) ? a : 0.0;
-      const double bd = a * bct[3 * (code >> kCodeIdxShift) + DIR];
-      const double inv = pivot_rcp(fma(-wm, cf, 1.0 + wm + wp + bd));
+      const double wp = co.wp(k);
+      const double inv = pivot_rcp(fma(-wm, cf, 1.0 + wm + wp + co.bd(k)));
       cf = wp * inv;
       df = fma(wm, df, e[k]) * inv;
       wm = wp;
     }
     {  // backward elimination, cell TS-1-k
       const int kb = TS - 1 - k;
-      const unsigned code = code_at(cw, kb);
-      const double wl = (code & Bits<DIR>::LM) ? a : 0.0;
-      const double bd = a * bct[3 * (code >> kCodeIdxShift) + DIR];
-      const double inv = pivot_rcp(fma(-wq, cb, 1.0 + wl + wq + bd));
+      const double wl = co.wm(kb);
+      const double inv = pivot_rcp(fma(-wq, cb, 1.0 + wl + wq + co.bd(kb)));
       cb = wl * inv;
       db = fma(wq, db, e[kb]) * inv;
       wq = wl;
@@ -195,14 +247,18 @@ __device__ __forceinline__ void tile_ghosts(const TileView& v, int b, int p, lon
   }
 }
 
-template <bool GEN>
-__device__ __forceinline__ TileCoord tile_of(const TileView& v) {
+constexpr int kTileHasBc = 1 << 30;      // tile-list entry: (has_bc << 30) | (ty << 16) | tx
+
+// CLS 0: clean tile, 1: general tile with uniform D, 2: tile of a variable-D plan
+template <int CLS>
+__device__ __forceinline__ TileCoord tile_of(const TileView& v, bool& has_bc) {
   TileCoord t;
   const int id = blockIdx.x;
   t.b = id % v.nfield;                          // fields of one tile are neighbours in launch order: shared codes hit L2
   // the list entry is wave-uniform; say so, or every row address of the tile becomes a per-lane 64-bit value
-  const int packed = __builtin_amdgcn_readfirstlane(v.tiles[GEN ? 1 : 0][id / v.nfield]);
-  t.ty = packed >> 16;
+  const int packed = __builtin_amdgcn_readfirstlane(v.tiles[CLS == 0 ? 0 : 1][id / v.nfield]);
+  has_bc = (packed & kTileHasBc) != 0;
+  t.ty = (packed >> 16) & 0x3fff;
   t.tx = packed & 0xffff;
   t.j0 = t.ty * TS;
   t.i0 = t.tx * TS;
@@ -216,14 +272,92 @@ __device__ __forceinline__ void stage_bct(const TileView& v, double* dst, int la
   __syncthreads();
 }
 
+__device__ __forceinline__ void load_line(const double* line, double (&w)[TS]) {
+  const double2* p = reinterpret_cast<const double2*>(line);      // 512-byte aligned by construction
+#pragma unroll
+  for (int q = 0; q < TS / 2; ++q) {
+    const double2 v2 = p[q];
+    w[2 * q] = v2.x;
+    w[2 * q + 1] = v2.y;
+  }
+}
+
+// Lane's line of the row-major (x-direction work, lane = row) / column-major (y-direction work, lane = column) planes.
+template <int DIR>
+__device__ __forceinline__ long line_offset(const TileView& v, const TileCoord& t, int lane) {
+  return DIR == 0 ? (long)(t.j0 + lane) * v.pnx + t.i0 : (long)(t.i0 + lane) * v.pny + t.j0;
+}
+
+// solve [+ explicit operator] along DIR on a general / variable-D tile
+template <int CLS, int DIR, bool SOLVE, bool EXPLICIT>
+__device__ __forceinline__ void line_work(const TileView& v, const TileCoord& t, int lane, bool has_bc, const double* bct,
+                                          double a, double (&e)[TS], double gl, double gr) {
+  const long off = line_offset<DIR>(v, t, lane);
+  unsigned cw[TS / 2];
+  load_codes((DIR == 0 ? v.code_r : v.code_c) + off, cw);
+  if (CLS == 1) {
+    const UniCoef<DIR> co{cw, a, bct};
+    if (SOLVE) solve_general(e, co, gl, gr);
+    if (SOLVE && EXPLICIT) codes_after(cw, e[0]);
+    if (EXPLICIT) explicit_general(e, co, gl, gr);
+  } else {
+    const long poff = (long)t.b * v.pny * v.pnx + off;
+    const double* wl = (DIR == 0 ? v.wx : v.wy) + poff;
+    const double wfirst = (DIR == 0 ? t.tx : t.ty) > 0 ? wl[-1] : 0.0;
+    if (has_bc) {     // wave-uniform
+      const StreamCoef<DIR> co{wl, (DIR == 0 ? v.rdx : v.rdy) + poff, cw, bct, wfirst, 0u};
+      if (SOLVE) solve_general(e, co, gl, gr);
+      if (EXPLICIT) explicit_general(e, co, gl, gr);
+    } else {
+      double w[TS];
+      load_line(wl, w);
+      const VarCoef<DIR> co{w, wfirst};
+      if (SOLVE) solve_general(e, co, gl, gr);
+      if (EXPLICIT) explicit_general(e, co, gl, gr);
+    }
+  }
+}
+
+// chunk-local eliminations along DIR: first / last entry of A_p^-1 e and the interface coefficients
+template <int CLS, int DIR>
+__device__ __forceinline__ void line_ends(const TileView& v, const TileCoord& t, int lane, bool has_bc, const double* bct,
+                                          double a, const double (&e)[TS], double& yf, double& yl, double& s, double& tt,
+                                          double& wm0, double& wp1) {
+  const long off = line_offset<DIR>(v, t, lane);
+  unsigned cw[TS / 2];
+  load_codes((DIR == 0 ? v.code_r : v.code_c) + off, cw);
+  if (CLS != 2) {
+    const UniCoef<DIR> co{cw, a, bct};
+    ends_general(e, co, yf, yl, s, tt);
+    wm0 = co.wm(0);
+    wp1 = co.wp(TS - 1);
+  } else {
+    const long poff = (long)t.b * v.pny * v.pnx + off;
+    const double* wl = (DIR == 0 ? v.wx : v.wy) + poff;
+    const double wfirst = (DIR == 0 ? t.tx : t.ty) > 0 ? wl[-1] : 0.0;
+    if (has_bc) {
+      const StreamCoef<DIR> co{wl, (DIR == 0 ? v.rdx : v.rdy) + poff, cw, bct, wfirst, 0u};
+      ends_general(e, co, yf, yl, s, tt);
+    } else {
+      double w[TS];
+      load_line(wl, w);
+      const VarCoef<DIR> co{w, wfirst};
+      ends_general(e, co, yf, yl, s, tt);
+    }
+    wm0 = wfirst;
+    wp1 = wl[TS - 1];
+  }
+}
+
 // x-kernel: finish the x-solve, [apply (I + a Lx) . + a S], store, chunk-local eliminations along y -> iface[1]
-template <bool GEN, bool EXPLICIT>
+template <int CLS, bool EXPLICIT>
 __global__ void __launch_bounds__(64) tile_x_kernel(TileView v, double* __restrict__ buf) {
   __shared__ double lds[LDS_DOUBLES];
   extern __shared__ double bct[];
   const int lane = threadIdx.x;
-  const TileCoord t = tile_of<GEN>(v);
-  if (GEN) stage_bct(v, bct, lane);
+  bool has_bc;
+  const TileCoord t = tile_of<CLS>(v, has_bc);
+  if (CLS != 0) stage_bct(v, bct, lane);
   const long ncell = (long)v.ny * v.nx;
   double* plane = buf + (long)t.b * ncell;
   const double a = as_const(v.alpha)[t.b];
@@ -233,14 +367,8 @@ __global__ void __launch_bounds__(64) tile_x_kernel(TileView v, double* __restri
   transpose64(e, lds, lane);
   double gl, gr;
   tile_ghosts<0>(v, t.b, t.tx, t.j0 + lane, lane < t.nr, gl, gr);
-  if (GEN) {
-    unsigned cw[TS / 2];
-    load_codes(v.code_r + (long)(t.j0 + lane) * v.pnx + t.i0, cw);
-    solve_general<0>(e, cw, a, bct, gl, gr);
-    if (EXPLICIT) {
-      codes_after(cw, e[0]);
-      explicit_general<0>(e, cw, a, bct, gl, gr);
-    }
+  if (CLS != 0) {
+    line_work<CLS, 0, true, EXPLICIT>(v, t, lane, has_bc, bct, a, e, gl, gr);
   } else {
     e[0] = fma(a, gl, e[0]);
     e[TS - 1] = fma(a, gr, e[TS - 1]);
@@ -250,11 +378,9 @@ __global__ void __launch_bounds__(64) tile_x_kernel(TileView v, double* __restri
   transpose64(e, lds, lane);
   store_cols(plane, t, v.nx, lane, e);
   double yf, yl;
-  if (GEN) {
-    unsigned cw[TS / 2];
-    double s, tt;
-    load_codes(v.code_c + (long)(t.i0 + lane) * v.pny + t.j0, cw);
-    ends_general<1>(e, cw, a, bct, yf, yl, s, tt);
+  if (CLS != 0) {
+    double s, tt, w0, w1;
+    line_ends<CLS, 1>(v, t, lane, has_bc, bct, a, e, yf, yl, s, tt, w0, w1);
   } else {
     dots64(e, tab, yf, yl);
   }
@@ -268,13 +394,14 @@ __global__ void __launch_bounds__(64) tile_x_kernel(TileView v, double* __restri
 // y-kernel.  MODE 0 (entry): src = u -> rhs1 = (I + a Ly) u + a S;  MODE 1 (carry): y-solve, rhs1' of the next step;
 //            MODE 2 (exit): y-solve, dst = u';  MODE 3 (reduce): only the x-eliminations of src (nothing stored).
 //            MODE 0, 1, 3 end with the chunk-local eliminations along x -> iface[0]
-template <bool GEN, int MODE>
+template <int CLS, int MODE>
 __global__ void __launch_bounds__(64) tile_y_kernel(TileView v, const double* src, double* dst) {   // src may alias dst
   __shared__ double lds[LDS_DOUBLES];
   extern __shared__ double bct[];
   const int lane = threadIdx.x;
-  const TileCoord t = tile_of<GEN>(v);
-  if (GEN) stage_bct(v, bct, lane);
+  bool has_bc;
+  const TileCoord t = tile_of<CLS>(v, has_bc);
+  if (CLS != 0) stage_bct(v, bct, lane);
   const long ncell = (long)v.ny * v.nx;
   const double* splane = src + (long)t.b * ncell;
   double* dplane = dst + (long)t.b * ncell;
@@ -291,14 +418,10 @@ __global__ void __launch_bounds__(64) tile_y_kernel(TileView v, const double* sr
   } else if (MODE != 3) {
     tile_ghosts<1>(v, t.b, t.ty, col, col_on, gu, gd);
   }
-  if (GEN) {
-    if (MODE != 3) {
-      unsigned cw[TS / 2];
-      load_codes(v.code_c + (long)(t.i0 + lane) * v.pny + t.j0, cw);
-      if (MODE != 0) solve_general<1>(e, cw, a, bct, gu, gd);
-      if (MODE == 1) codes_after(cw, e[0]);
-      if (MODE != 2) explicit_general<1>(e, cw, a, bct, gu, gd);
-    }
+  if (CLS != 0) {
+    if (MODE == 0) line_work<CLS, 1, false, true>(v, t, lane, has_bc, bct, a, e, gu, gd);
+    if (MODE == 1) line_work<CLS, 1, true, true>(v, t, lane, has_bc, bct, a, e, gu, gd);
+    if (MODE == 2) line_work<CLS, 1, true, false>(v, t, lane, has_bc, bct, a, e, gu, gd);
   } else {
     if (MODE == 1 || MODE == 2) {
       e[0] = fma(a, gu, e[0]);
@@ -311,11 +434,9 @@ __global__ void __launch_bounds__(64) tile_y_kernel(TileView v, const double* sr
   if (MODE == 2) return;
   transpose64(e, lds, lane);
   double yf, yl;
-  if (GEN) {
-    unsigned cw[TS / 2];
-    double s, tt;
-    load_codes(v.code_r + (long)(t.j0 + lane) * v.pnx + t.i0, cw);
-    ends_general<0>(e, cw, a, bct, yf, yl, s, tt);
+  if (CLS != 0) {
+    double s, tt, w0, w1;
+    line_ends<CLS, 0>(v, t, lane, has_bc, bct, a, e, yf, yl, s, tt, w0, w1);
   } else {
     dots64(e, tab, yf, yl);
   }
@@ -327,63 +448,83 @@ __global__ void __launch_bounds__(64) tile_y_kernel(TileView v, const double* sr
 }
 
 // Plan creation: interface coefficients (s, t) of every chunk of every non-empty tile in both directions, and the
-// largest far coupling (atomic max over the bit pattern of a non-negative double).
-__global__ void __launch_bounds__(64) tile_setup_kernel(TileView v, int cls, unsigned long long* far_bits) {
+// largest far coupling (atomic max over the bit pattern of a non-negative double).  CLS 1 (codes; also right for clean
+// tiles) or 2 (variable D); `list` selects the tile list.
+template <int CLS>
+__global__ void __launch_bounds__(64) tile_setup_kernel(TileView v, int list, unsigned long long* far_bits) {
   extern __shared__ double bct[];
   const int lane = threadIdx.x;
   TileCoord t;
-  {
-    const int id = blockIdx.x;
-    t.b = id % v.nfield;
-    const int packed = __builtin_amdgcn_readfirstlane(v.tiles[cls][id / v.nfield]);
-    t.ty = packed >> 16;
-    t.tx = packed & 0xffff;
-    t.j0 = t.ty * TS;
-    t.i0 = t.tx * TS;
-    t.nr = min(TS, v.ny - t.j0);
-    t.nc = min(TS, v.nx - t.i0);
-  }
+  const int id = blockIdx.x;
+  t.b = id % v.nfield;
+  const int packed = __builtin_amdgcn_readfirstlane(v.tiles[list][id / v.nfield]);
+  const bool has_bc = (packed & kTileHasBc) != 0;
+  t.ty = (packed >> 16) & 0x3fff;
+  t.tx = packed & 0xffff;
+  t.j0 = t.ty * TS;
+  t.i0 = t.tx * TS;
+  t.nr = min(TS, v.ny - t.j0);
+  t.nc = min(TS, v.nx - t.i0);
   stage_bct(v, bct, lane);
   const double a = v.alpha[t.b];
   double far = 0.0;
-  for (int dir = 0; dir < 2; ++dir) {
-    unsigned cw[TS / 2];
-    if (dir == 0) load_codes(v.code_r + (long)(t.j0 + lane) * v.pnx + t.i0, cw);
-    else load_codes(v.code_c + (long)(t.i0 + lane) * v.pny + t.j0, cw);
-    double e[TS];
+  double e[TS];
+  double yf, yl, s, tt, yf2, yl2, s2, t2, wm0, wp1;
+  // direction x (lane = row)
 #pragma unroll
-    for (int k = 0; k < TS; ++k) e[k] = k == 0 ? 1.0 : 0.0;
-    double yf, yl, s, tt, yf2, yl2;
-    const unsigned c0 = code_at(cw, 0), c1 = code_at(cw, TS - 1);
-    double wm0, wp1;
-    if (dir == 0) {
-      ends_general<0>(e, cw, a, bct, yf, yl, s, tt);
-      e[0] = 0.0; e[TS - 1] = 1.0;
-      double s2, t2;
-      ends_general<0>(e, cw, a, bct, yf2, yl2, s2, t2);
-      wm0 = (c0 & QP_FLAG_LINK_XM) ? a : 0.0;
-      wp1 = (c1 & QP_FLAG_LINK_XP) ? a : 0.0;
-    } else {
-      ends_general<1>(e, cw, a, bct, yf, yl, s, tt);
-      e[0] = 0.0; e[TS - 1] = 1.0;
-      double s2, t2;
-      ends_general<1>(e, cw, a, bct, yf2, yl2, s2, t2);
-      wm0 = (c0 & QP_FLAG_LINK_YM) ? a : 0.0;
-      wp1 = (c1 & QP_FLAG_LINK_YP) ? a : 0.0;
-    }
-    far = fmax(far, fmax(fabs(wm0 * yl), fabs(wp1 * yf2)));      // wm_first g[last], wp_last h[first]
-    const int P = dir == 0 ? v.px : v.py, p = dir == 0 ? t.tx : t.ty;
-    const long nl = dir == 0 ? v.ny : v.nx;
-    const long line = dir == 0 ? t.j0 + lane : t.i0 + lane;
-    if (lane < (dir == 0 ? t.nr : t.nc)) {
-      double* cf = v.coef[dir] + (long)t.b * (2 * P + 2) * nl + line;
-      cf[(long)(2 * p + 1) * nl] = tt;
-      cf[(long)(2 * p + 2) * nl] = s;
-    }
+  for (int k = 0; k < TS; ++k) e[k] = k == 0 ? 1.0 : 0.0;
+  line_ends<CLS, 0>(v, t, lane, has_bc, bct, a, e, yf, yl, s, tt, wm0, wp1);
+  e[0] = 0.0;
+  e[TS - 1] = 1.0;
+  line_ends<CLS, 0>(v, t, lane, has_bc, bct, a, e, yf2, yl2, s2, t2, wm0, wp1);
+  far = fmax(far, fmax(fabs(wm0 * yl), fabs(wp1 * yf2)));      // wm_first g[last], wp_last h[first]
+  if (lane < t.nr) {
+    double* cf = v.coef[0] + (long)t.b * (2 * v.px + 2) * v.ny + t.j0 + lane;
+    cf[(long)(2 * t.tx + 1) * v.ny] = tt;
+    cf[(long)(2 * t.tx + 2) * v.ny] = s;
+  }
+  // direction y (lane = column)
+  e[TS - 1] = 0.0;
+  e[0] = 1.0;
+  line_ends<CLS, 1>(v, t, lane, has_bc, bct, a, e, yf, yl, s, tt, wm0, wp1);
+  e[0] = 0.0;
+  e[TS - 1] = 1.0;
+  line_ends<CLS, 1>(v, t, lane, has_bc, bct, a, e, yf2, yl2, s2, t2, wm0, wp1);
+  far = fmax(far, fmax(fabs(wm0 * yl), fabs(wp1 * yf2)));
+  if (lane < t.nc) {
+    double* cf = v.coef[1] + (long)t.b * (2 * v.py + 2) * v.nx + t.i0 + lane;
+    cf[(long)(2 * t.ty + 1) * v.nx] = tt;
+    cf[(long)(2 * t.ty + 2) * v.nx] = s;
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) far = fmax(far, __shfl_xor(far, off));
   if (lane == 0) atomicMax(far_bits, (unsigned long long)__double_as_longlong(far));
+}
+
+// Variable-D plans: face weights r * harmonic mean (solver.py:283) and r D per cell, in the row-major and column-major
+// padded layouts the sweeps read; one thread per padded cell and field.
+__global__ void __launch_bounds__(256) tile_var_weights_kernel(TileView v, const double* __restrict__ dfield, double r,
+                                                               double* wx, double* wy, double* rdx, double* rdy) {
+  const long pcell = (long)v.pny * v.pnx;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= pcell * v.nfield) return;
+  const int b = (int)(gid / pcell);
+  const long q = gid - (long)b * pcell;
+  const int j = (int)(q / v.pnx), i = (int)(q - (long)j * v.pnx);
+  double d = 0.0, fx = 0.0, fy = 0.0;
+  if (j < v.ny && i < v.nx) {
+    const unsigned code = v.code_r[q];
+    const double* D = dfield + (long)b * v.ny * v.nx;
+    const long p = (long)j * v.nx + i;
+    if (code & QP_FLAG_ACTIVE) d = D[p];
+    if (code & QP_FLAG_LINK_XP) fx = r * face_mean(d, D[p + 1]);
+    if (code & QP_FLAG_LINK_YP) fy = r * face_mean(d, D[p + v.nx]);
+  }
+  const long qc = (long)i * v.pny + j;
+  wx[gid] = fx;
+  rdx[gid] = r * d;
+  wy[(long)b * pcell + qc] = fy;
+  rdy[(long)b * pcell + qc] = r * d;
 }
 
 }  // namespace qp
@@ -407,18 +548,21 @@ int qp_adi_tile_plan_destroy(qp_adi_tile_plan* plan) {
   return QP_OK;
 }
 
-int qp_adi_tile_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, const double* dcoef_host,
-                            const uint8_t* flags, const double* ex, const double* ey, const double* sx, const double* sy,
-                            qp_adi_tile_plan** out) {
+static int tile_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, const double* dcoef_host,
+                            const double* dfield_dev, const uint8_t* flags, const double* ex, const double* ey,
+                            const double* sx, const double* sy, qp_adi_tile_plan** out) {
   QP_REQUIRE(out != nullptr, "out is NULL");
   *out = nullptr;
   QP_REQUIRE(ny > 0 && nx > 0 && nfield > 0, "ny, nx, nfield must be positive");
-  QP_REQUIRE(r > 0.0 && dcoef_host && flags && ex && ey && sx && sy, "r must be positive; host arrays non-NULL");
+  QP_REQUIRE(r > 0.0 && flags && ex && ey && sx && sy, "r must be positive; host arrays non-NULL");
+  QP_REQUIRE((dcoef_host != nullptr) != (dfield_dev != nullptr), "exactly one of dcoef / dfield must be given");
   using namespace qp;
+  const bool var = dfield_dev != nullptr;
   const int py = (ny + TS - 1) / TS, px = (nx + TS - 1) / TS;
-  QP_REQUIRE(py < 32768 && px < 65536, "grid too large for the packed tile index");
+  QP_REQUIRE(py < 16384 && px < 65536, "grid too large for the packed tile index");
   const int pny = py * TS, pnx = px * TS;
-  for (int b = 0; b < nfield; ++b) QP_REQUIRE(dcoef_host[b] >= 0.0, "diffusion coefficients must be >= 0");
+  if (!var)
+    for (int b = 0; b < nfield; ++b) QP_REQUIRE(dcoef_host[b] >= 0.0, "diffusion coefficients must be >= 0");
 
   // codes and the boundary-term table
   std::map<std::tuple<double, double, double>, int> bc_index;
@@ -465,24 +609,25 @@ int qp_adi_tile_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, co
   int counts[3] = {0, 0, 0};
   for (int ty = 0; ty < py; ++ty) {
     for (int tx = 0; tx < px; ++tx) {
-      bool any = false, clean = true;
+      bool any = false, clean = true, has_bc = false;
       for (int j = ty * TS; j < ty * TS + TS; ++j) {
         const uint16_t* row = &code_r[(size_t)j * pnx + tx * TS];
         for (int k = 0; k < TS; ++k) {
           any = any || row[k] != 0;
           clean = clean && row[k] == 31u;
+          has_bc = has_bc || (row[k] >> kCodeIdxShift) != 0;
         }
       }
       if (!any) { counts[0]++; continue; }
-      const int cls = clean ? 0 : 1;
+      const int cls = (clean && !var) ? 0 : 1;      // variable D: no tile shares coefficients with another
       counts[1 + cls]++;
-      lists[cls].push_back((ty << 16) | tx);
+      lists[cls].push_back((has_bc ? kTileHasBc : 0) | (ty << 16) | tx);
     }
   }
   // interior-chunk tables of the rectangle path (chunk 1 of a 3-chunk line; end faces irrelevant)
   std::vector<double> alpha(nfield), tab((size_t)nfield * T_NSLOT * TS);
   const DirSpec spec{3 * TS, 3, 0.0, 0.0, 0.0, 0.0};
-  for (int b = 0; b < nfield; ++b) {
+  for (int b = 0; b < nfield && !var; ++b) {
     alpha[b] = r * dcoef_host[b];
     double ends[4];
     build_chunk_table(spec, alpha[b], 1, &tab[(size_t)b * T_NSLOT * TS], ends);
@@ -492,6 +637,8 @@ int qp_adi_tile_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, co
   TileView& v = plan->view;
   v.ny = ny; v.nx = nx; v.nfield = nfield; v.py = py; v.px = px; v.pny = pny; v.pnx = pnx;
   v.nbc = (int)bc_index.size();
+  v.var = var ? 1 : 0;
+  v.wx = v.wy = v.rdx = v.rdy = nullptr;
   plan->ncell = (long)ny * nx;
   plan->bct_bytes = bct.size() * sizeof(double);
   for (int k = 0; k < 3; ++k) plan->counts[k] = counts[k];
@@ -528,16 +675,32 @@ int qp_adi_tile_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, co
   }
   plan->d_work = (double*)zalloc((size_t)nfield * plan->ncell * sizeof(double));
   unsigned long long* d_far = (unsigned long long*)zalloc(sizeof(unsigned long long));
+  double* wplanes[4] = {nullptr, nullptr, nullptr, nullptr};
+  const size_t pplane = (size_t)nfield * pny * pnx;
+  if (var) {
+    // one leading pad element per array: the first line reads w[-1] only when a previous chunk exists, but keep the
+    // address valid for the hardware prefetch of partial tiles anyway
+    for (int k = 0; k < 4; ++k) wplanes[k] = (double*)zalloc(pplane * sizeof(double));
+    v.wx = wplanes[0]; v.wy = wplanes[1]; v.rdx = wplanes[2]; v.rdy = wplanes[3];
+  }
   if (!ok) {
     (void)hipGetLastError();
     qp_adi_tile_plan_destroy(plan);
     set_error("qp_adi_tile_plan_create: device allocation or upload failed");
     return QP_ERR_ALLOC;
   }
-  for (int c = 0; c < 2; ++c)
-    if (v.ntiles[c] > 0)
-      hipLaunchKernelGGL(tile_setup_kernel, dim3((unsigned)((long)v.ntiles[c] * nfield)), dim3(64), plan->bct_bytes, 0, v,
-                         c, d_far);
+  if (var) {
+    hipLaunchKernelGGL(tile_var_weights_kernel, dim3((unsigned)((pplane + 255) / 256)), dim3(256), 0, 0, v, dfield_dev, r,
+                       wplanes[0], wplanes[1], wplanes[2], wplanes[3]);
+    if (v.ntiles[1] > 0)
+      hipLaunchKernelGGL(tile_setup_kernel<2>, dim3((unsigned)((long)v.ntiles[1] * nfield)), dim3(64), plan->bct_bytes, 0,
+                         v, 1, d_far);
+  } else {
+    for (int c = 0; c < 2; ++c)
+      if (v.ntiles[c] > 0)
+        hipLaunchKernelGGL(tile_setup_kernel<1>, dim3((unsigned)((long)v.ntiles[c] * nfield)), dim3(64), plan->bct_bytes,
+                           0, v, c, d_far);
+  }
   unsigned long long far_bits = 0;
   if (hipMemcpy(&far_bits, d_far, sizeof(far_bits), hipMemcpyDeviceToHost) != hipSuccess || hipGetLastError() != hipSuccess) {
     qp_adi_tile_plan_destroy(plan);
@@ -557,6 +720,20 @@ int qp_adi_tile_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, co
   return QP_OK;
 }
 
+int qp_adi_tile_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, const double* dcoef_host,
+                            const uint8_t* flags, const double* ex, const double* ey, const double* sx, const double* sy,
+                            qp_adi_tile_plan** out) {
+  QP_REQUIRE(dcoef_host != nullptr, "dcoef_host is NULL");
+  return tile_plan_create(ny, nx, nfield, r, dcoef_host, nullptr, flags, ex, ey, sx, sy, out);
+}
+
+int qp_adi_tile_plan_create_var(int32_t ny, int32_t nx, int32_t nfield, double r, const double* dfield,
+                                const uint8_t* flags, const double* ex, const double* ey, const double* sx,
+                                const double* sy, qp_adi_tile_plan** out) {
+  QP_REQUIRE(dfield != nullptr, "dfield is NULL");
+  return tile_plan_create(ny, nx, nfield, r, nullptr, dfield, flags, ex, ey, sx, sy, out);
+}
+
 int qp_adi_tile_plan_info(const qp_adi_tile_plan* plan, int32_t* counts, double* far) {
   QP_REQUIRE(plan && counts, "plan and counts must be non-NULL");
   for (int k = 0; k < 3; ++k) counts[k] = plan->counts[k];
@@ -572,10 +749,13 @@ template <bool EXPLICIT>
 static void launch_x(const qp_adi_tile_plan* plan, double* buf, hipStream_t stream) {
   const TileView& v = plan->view;
   if (v.ntiles[0] > 0)
-    hipLaunchKernelGGL((tile_x_kernel<false, EXPLICIT>), dim3((unsigned)((long)v.ntiles[0] * v.nfield)), dim3(64), 0, stream,
+    hipLaunchKernelGGL((tile_x_kernel<0, EXPLICIT>), dim3((unsigned)((long)v.ntiles[0] * v.nfield)), dim3(64), 0, stream,
                        v, buf);
-  if (v.ntiles[1] > 0)
-    hipLaunchKernelGGL((tile_x_kernel<true, EXPLICIT>), dim3((unsigned)((long)v.ntiles[1] * v.nfield)), dim3(64),
+  if (v.ntiles[1] > 0 && !v.var)
+    hipLaunchKernelGGL((tile_x_kernel<1, EXPLICIT>), dim3((unsigned)((long)v.ntiles[1] * v.nfield)), dim3(64),
+                       plan->bct_bytes, stream, v, buf);
+  if (v.ntiles[1] > 0 && v.var)
+    hipLaunchKernelGGL((tile_x_kernel<2, EXPLICIT>), dim3((unsigned)((long)v.ntiles[1] * v.nfield)), dim3(64),
                        plan->bct_bytes, stream, v, buf);
 }
 
@@ -583,10 +763,13 @@ template <int MODE>
 static void launch_y(const qp_adi_tile_plan* plan, const double* src, double* dst, hipStream_t stream) {
   const TileView& v = plan->view;
   if (v.ntiles[0] > 0)
-    hipLaunchKernelGGL((tile_y_kernel<false, MODE>), dim3((unsigned)((long)v.ntiles[0] * v.nfield)), dim3(64), 0, stream, v,
+    hipLaunchKernelGGL((tile_y_kernel<0, MODE>), dim3((unsigned)((long)v.ntiles[0] * v.nfield)), dim3(64), 0, stream, v,
                        src, dst);
-  if (v.ntiles[1] > 0)
-    hipLaunchKernelGGL((tile_y_kernel<true, MODE>), dim3((unsigned)((long)v.ntiles[1] * v.nfield)), dim3(64),
+  if (v.ntiles[1] > 0 && !v.var)
+    hipLaunchKernelGGL((tile_y_kernel<1, MODE>), dim3((unsigned)((long)v.ntiles[1] * v.nfield)), dim3(64),
+                       plan->bct_bytes, stream, v, src, dst);
+  if (v.ntiles[1] > 0 && v.var)
+    hipLaunchKernelGGL((tile_y_kernel<2, MODE>), dim3((unsigned)((long)v.ntiles[1] * v.nfield)), dim3(64),
                        plan->bct_bytes, stream, v, src, dst);
 }
 

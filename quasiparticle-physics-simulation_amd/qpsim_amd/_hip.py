@@ -75,6 +75,8 @@ SIGNATURES = {
     "qp_collision_register_kernel_available": (C.c_int, [C.c_int32]),
     "qp_adi_tile_plan_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.POINTER(C.c_double), c_dp, c_dp,
                                           c_dp, c_dp, c_dp, C.POINTER(C.POINTER(TilePlan))]),
+    "qp_adi_tile_plan_create_var": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_double, c_dp, c_dp, c_dp, c_dp, c_dp,
+                                              c_dp, C.POINTER(C.POINTER(TilePlan))]),
     "qp_adi_tile_plan_destroy": (C.c_int, [C.POINTER(TilePlan)]),
     "qp_adi_tile_plan_info": (C.c_int, [C.POINTER(TilePlan), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "qp_adi_tile_steps": (C.c_int, [C.POINTER(TilePlan), c_dp, C.c_int32, c_dp]),

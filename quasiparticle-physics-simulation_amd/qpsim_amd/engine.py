@@ -230,15 +230,21 @@ class RectPlan:
 class TilePlan:
     """Owner of a ``qp_adi_tile_plan`` (tiled ADI path for masked grids with one diffusivity per field)."""
 
-    def __init__(self, lib, geom: CompiledGeometry, nfield, r, dcoef):
+    def __init__(self, lib, geom: CompiledGeometry, nfield, r, dcoef=None, dfield_dev=None):
+        """``dcoef``: one diffusivity per field (host values) or ``dfield_dev``: device tensor [nfield, ncell]."""
         self._lib = lib
         self._h = C.POINTER(_hip.TilePlan)()
         ny, nx = geom.mask.shape
-        dc = (C.c_double * nfield)(*[float(v) for v in dcoef])
         host = [np.ascontiguousarray(geom.flags, dtype=np.uint8)] + [
             np.ascontiguousarray(a, dtype=np.float64) for a in (geom.ex, geom.ey, geom.sx, geom.sy)]
-        _hip.check(lib.qp_adi_tile_plan_create(ny, nx, nfield, float(r), dc, *[a.ctypes.data for a in host],
-                                               C.byref(self._h)), "qp_adi_tile_plan_create")
+        if dfield_dev is None:
+            dc = (C.c_double * nfield)(*[float(v) for v in dcoef])
+            _hip.check(lib.qp_adi_tile_plan_create(ny, nx, nfield, float(r), dc, *[a.ctypes.data for a in host],
+                                                   C.byref(self._h)), "qp_adi_tile_plan_create")
+        else:
+            _hip.check(lib.qp_adi_tile_plan_create_var(ny, nx, nfield, float(r), int(dfield_dev.data_ptr()),
+                                                       *[a.ctypes.data for a in host], C.byref(self._h)),
+                       "qp_adi_tile_plan_create_var")
         counts = (C.c_int32 * 3)()
         far = C.c_double()
         _hip.check(lib.qp_adi_tile_plan_info(self._h, counts, C.byref(far)), "qp_adi_tile_plan_info")
@@ -290,10 +296,13 @@ class DiffusionOperator:
         # 64-cell chunks to decouple (then the per-line kernels below remain)
         self.tile = None
         self.tile_refused = None
-        if self.rect is None and allow_fast and allow_tile and dcoef is not None and self.dt > 0.0:
+        if self.rect is None and allow_fast and allow_tile and self.dt > 0.0:
             with torch.cuda.device(engine.device):
                 try:
-                    self.tile = TilePlan(engine.lib, engine.geom, self.nfield, self.r, np.asarray(dcoef, dtype=float))
+                    if dcoef is not None:
+                        self.tile = TilePlan(engine.lib, engine.geom, self.nfield, self.r, np.asarray(dcoef, dtype=float))
+                    else:
+                        self.tile = TilePlan(engine.lib, engine.geom, self.nfield, self.r, dfield_dev=self.dfield)
                 except _hip.QPHipError as exc:
                     if exc.status != -3:      # QP_ERR_UNSUPPORTED
                         raise
