@@ -38,7 +38,7 @@ class ADIWorkload:
     """N x N scalar CN-ADI diffusion; `chunk` consecutive steps per library call share the carried state."""
 
     def __init__(self, N: int, device, nfield: int = 1, ring: bool = False):
-        self.N, self.nfield = N, nfield
+        self.N, self.nfield, self.ring = N, nfield, ring
         if ring:
             mask = ring_mask(N)
             edges = extract_edge_segments(mask)
@@ -71,15 +71,23 @@ class ADIWorkload:
     run_steps = run
 
     def _pmc_traffic(self):
-        """HBM bytes per sweep launch from the committed PMC summary (profiles/, separate rocprofv3 --pmc passes of this
-        same command); only the configuration it was measured on gets a number."""
+        """HBM bytes per sweep from the committed PMC summaries (profiles/, separate rocprofv3 --pmc passes of this same
+        command); only the configurations that were measured get a number."""
         import json
         from pathlib import Path
-        f = Path(__file__).resolve().parents[2] / "profiles" / "r01_adi4096_pmc.json"
-        if self.N != 4096 or self.nfield != 1 or self.op.rect is None or not f.exists():
+        prof = Path(__file__).resolve().parents[2] / "profiles"
+        if self.N != 4096 or self.nfield != 1:
             return None
-        k = json.loads(f.read_text())["kernels"]
-        return 0.5 * (k["qp::rect_x_kernel"]["hbm_bytes_per_launch"] + k["qp::rect_y_kernel<1>"]["hbm_bytes_per_launch"])
+        if self.op.rect is not None and (prof / "r01_adi4096_pmc.json").exists():
+            k = json.loads((prof / "r01_adi4096_pmc.json").read_text())["kernels"]
+            return 0.5 * (k["qp::rect_x_kernel"]["hbm_bytes_per_launch"] + k["qp::rect_y_kernel<1>"]["hbm_bytes_per_launch"])
+        if self.ring and self.op.tile is not None and (prof / "r01_ring4096_pmc.json").exists():
+            k = json.loads((prof / "r01_ring4096_pmc.json").read_text())["kernels"]
+            pick = lambda frag: sum(v["hbm_bytes_per_launch"] for name, v in k.items() if frag in name)  # noqa: E731
+            # one sweep = clean + general launch; average of the x sweep and the carried y sweep
+            return 0.5 * (pick("tile_x_kernel<0, true>") + pick("tile_x_kernel<1, true>") + pick("tile_y_kernel<0, 1>")
+                          + pick("tile_y_kernel<1, 1>"))
+        return None
 
     def roofline(self, nrep: int) -> dict:
         """Average duration of one sweep kernel launch (HIP events on the launch stream) vs algorithmic bytes."""
@@ -194,6 +202,18 @@ class CoupledWorkload:
                 raise ValueError("Pauli guard tripped in the benchmark state")
             self.max_occ = max(self.max_occ, mx)
 
+    def _pmc_traffic(self):
+        """HBM bytes per collision call from the committed PMC summary of `--workload c3` (profiles/r01_c3_pmc.json)."""
+        import json
+        from pathlib import Path
+        f = Path(__file__).resolve().parents[2] / "profiles" / "r01_c3_pmc.json"
+        if not (self.N == 4096 and self.ne == 12 and self.members == 1 and self.upd and self.en_s and f.exists()):
+            return None
+        for name, v in json.loads(f.read_text())["kernels"].items():
+            if "collision_diag_kernel<12, true, true, true>" in name:
+                return v["hbm_bytes_per_launch"]
+        return None
+
     def roofline(self, nrep: int) -> dict:
         """Dominant kernel = the collision update (two calls per step): HIP-event time per call vs its plane traffic."""
         torch = self.eng.torch
@@ -210,7 +230,7 @@ class CoupledWorkload:
         achieved = self.coll_bytes_per_call / per_call / 1e9
         pairs = self.ne * self.ne
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "kernel": {"register": "collision_diag_kernel", "wave": "collision_wave_kernel",
+                "traffic": self._pmc_traffic(), "kernel": {"register": "collision_diag_kernel", "wave": "collision_wave_kernel",
                                             "generic": "collision_generic_kernel"}[self.tab["kernel"]],
                 "bytes_per_launch": self.coll_bytes_per_call, "avg_launch_us": per_call * 1e6,
                 "pixel_updates_per_s": self.npix / per_call,
