@@ -150,6 +150,10 @@ int qp_euler_collision(int32_t ne, int64_t ncell, const double* state_in, double
  * solver.py:910-916,1464), or state += scale * g[f][p] (custom generation evaluated on the host).
  */
 int qp_add_constant(const uint8_t* flags, int64_t ncell, int32_t nfield, double* state, double amount, void* stream);
+/* out[f][p] = scale * in[f][p] inside the mask, NaN outside: the NaN-padded [ny, nx] frames of reconstruct_field
+ * (solver.py:215-218, store block :1479-1494) formed on the device, so a stored state crosses PCIe once, ready to hand out. */
+int qp_nan_pad(const uint8_t* flags, int64_t ncell, int32_t nfield, const double* in, double scale, double* out,
+               void* stream);
 int qp_add_scaled(int64_t n, double* state, const double* g, double scale, void* stream);
 
 /*

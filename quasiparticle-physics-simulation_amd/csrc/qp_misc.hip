@@ -13,6 +13,17 @@ __global__ void __launch_bounds__(256) add_constant_kernel(const uint8_t* __rest
   }
 }
 
+// out[f][p] = inside the mask ? scale * in[f][p] : NaN  (frames as the reference returns them, reconstruct_field)
+__global__ void __launch_bounds__(256) nan_pad_kernel(const uint8_t* __restrict__ flags, long ncell, int nfield,
+                                                      const double* __restrict__ in, double scale,
+                                                      double* __restrict__ out) {
+  const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < ncell; p += (long)gridDim.x * blockDim.x) {
+    const bool on = flags[p] & QP_FLAG_ACTIVE;
+    for (int f = 0; f < nfield; ++f) out[(long)f * ncell + p] = on ? scale * in[(long)f * ncell + p] : qnan;
+  }
+}
+
 __global__ void __launch_bounds__(256) add_scaled_kernel(long n, double* __restrict__ s,
                                                          const double* __restrict__ g, double scale) {
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x)
@@ -169,6 +180,14 @@ int qp_add_constant(const uint8_t* flags, int64_t ncell, int32_t nfield, double*
   hipLaunchKernelGGL(qp::add_constant_kernel, dim3(qp::grid_for(ncell * nfield)), dim3(256), 0, (hipStream_t)stream,
                      flags, (long)ncell, (int)nfield, state, amount);
   return qp::check_launch("qp_add_constant");
+}
+
+int qp_nan_pad(const uint8_t* flags, int64_t ncell, int32_t nfield, const double* in, double scale, double* out,
+               void* stream) {
+  QP_REQUIRE(flags && in && out && ncell > 0 && nfield > 0, "bad arguments");
+  hipLaunchKernelGGL(qp::nan_pad_kernel, dim3(qp::grid_for(ncell)), dim3(256), 0, (hipStream_t)stream, flags, (long)ncell,
+                     (int)nfield, in, scale, out);
+  return qp::check_launch("qp_nan_pad");
 }
 
 int qp_add_scaled(int64_t n, double* state, const double* g, double scale, void* stream) {

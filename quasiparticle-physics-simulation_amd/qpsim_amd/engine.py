@@ -355,6 +355,19 @@ class Engine:
     def download_packed(self, planes) -> np.ndarray:
         return planes.detach().cpu().numpy()[:, self.mask_flat]
 
+    def download_frames(self, planes, scale: float = 1.0) -> np.ndarray:
+        """[nfield, ncell] device planes -> host [nfield, ny, nx] frames, NaN outside the mask (reconstruct_field), times
+        `scale`; the padding happens on the device, the host only receives."""
+        planes = planes.reshape(-1, self.ncell)
+        out = self.empty(planes.shape[0], self.ncell)
+        _hip.check(self.lib.qp_nan_pad(_ptr(self.d_flags), self.ncell, planes.shape[0], _ptr(planes), float(scale),
+                                       _ptr(out), self.stream), "qp_nan_pad")
+        return out.cpu().numpy().reshape(planes.shape[0], self.ny, self.nx)
+
+    def masked_sum(self, plane) -> float:
+        """Sum of one plane over the cells inside the mask (holes hold 0 by invariant)."""
+        return float(plane.sum().item())
+
     # -- diffusion --------------------------------------------------------------------------------------------
     def stencil(self, op: DiffusionOperator, u, out, c0, cx, cy, cs, rin=None, cr=0.0):
         _hip.check(self.lib.qp_stencil_combine(C.byref(op.desc), op.r, _ptr(u), _ptr(rin), _ptr(out), c0, cx, cy, cs,

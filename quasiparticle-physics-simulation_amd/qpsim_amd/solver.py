@@ -161,6 +161,19 @@ def _crop_to_bounding_box(mask: np.ndarray, edges: list[EdgeSegment]):
     return np.ascontiguousarray(mask[r0:r1, c0:c1]), shifted
 
 
+def _device_frames(eng, planes, mask: np.ndarray) -> np.ndarray:
+    """Device planes -> host [n, ny, nx] frames on the FULL mask, NaN outside the interior (reconstruct_field semantics).
+    The padding is done on the device for the engine's grid; a cropped engine grid is embedded into the full frame."""
+    fr = eng.download_frames(planes)
+    if fr.shape[1:] == mask.shape:
+        return fr
+    r0 = int(np.flatnonzero(mask.any(axis=1))[0])
+    c0 = int(np.flatnonzero(mask.any(axis=0))[0])
+    out = np.full((fr.shape[0],) + mask.shape, np.nan)
+    out[:, r0:r0 + fr.shape[1], c0:c0 + fr.shape[2]] = fr
+    return out
+
+
 def _step_plan(total_time: float, dt: float) -> tuple[int, float, int]:
     """(full steps, remainder dt or 0, total steps) (solver.py:1085-1089)."""
     full = int(np.floor(total_time / dt + 1e-12))
@@ -425,9 +438,9 @@ def run_2d_crank_nicolson(
     ph_widths = integration_widths_from_centers(omega_bins, fallback_width=dE) if want_ph else None
 
     def snapshot_phonons() -> None:                              # solver.py:1354-1360
-        ph = eng.download_packed(phonon)
-        ph_eframes.append([reconstruct_field(mask, ph[i]) for i in range(ph.shape[0])])
-        ph_frames.append(reconstruct_field(mask, np.sum(ph * ph_widths[:, None], axis=0)))
+        ph = _device_frames(eng, phonon, mask)                   # NaN-padded on the device
+        ph_eframes.append(list(ph))
+        ph_frames.append(_device_frames(eng, eng.weighted_sum(phonon, ph_widths), mask)[0])
 
     times: list[float] = [0.0]
     frames: list[np.ndarray] = []
@@ -435,14 +448,13 @@ def run_2d_crank_nicolson(
     mass: list[float] = []
 
     def store() -> np.ndarray:                                   # solver.py:1367-1374, 1480-1489
-        host = eng.download_packed(state)
-        integrated = np.sum(host, axis=0) * dE
-        frame = reconstruct_field(mask, integrated)
+        # frames are formed on the device (energy integral, NaN padding) and cross PCIe once, ready to hand out
+        frame = _device_frames(eng, eng.energy_integral(state, dE), mask)[0]
         frames.append(frame)
-        energy_frames.append([reconstruct_field(mask, host[i]) for i in range(NE)])
+        energy_frames.append(list(_device_frames(eng, state, mask)))
         if want_ph:
             snapshot_phonons()
-        mass.append(float(np.sum(integrated) * dx * dx))
+        mass.append(float(np.sum(frame[mask]) * dx * dx))        # same summation order as the reference's packed sum
         return frame
 
     _notify(progress_callback, 0.0, store())
@@ -522,10 +534,9 @@ def _run_scalar(eng: Engine, mask, initial_field, D, dt, rem, full_steps, total_
             diffuser.step(u, final)
         t += dt_step
         if stored(step):
-            cur = eng.download_packed(u)[0]
             times.append(float(t))
-            frames.append(reconstruct_field(mask, cur))
-            mass.append(float(np.sum(cur) * dx * dx))
+            frames.append(_device_frames(eng, u, mask)[0])
+            mass.append(float(np.sum(frames[-1][mask]) * dx * dx))
             _notify(progress_callback, t, frames[-1])
     limits = _color_limits(frames)
     if phonon_history_out is not None:
