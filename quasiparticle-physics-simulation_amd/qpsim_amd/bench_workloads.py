@@ -179,28 +179,30 @@ class CoupledWorkload:
                                              eng.stream), "qp_collision_step")
         self.state, self.alt = self.alt, self.state
 
-    def _guard(self):
-        """Pauli guard over all members (device reduction, result read back on the host as the reference does)."""
-        import ctypes as C
-        from . import _hip
-        eng = self.eng
-        _hip.check(eng.lib.qp_pauli_stats(int(self.state.data_ptr()), int(self.tab["rho"].data_ptr()), 0,
-                                          int(self.coll_flags.data_ptr()), self.ne, 1, self.npix, 1e-18,
-                                          int(eng._ws.data_ptr()), int(eng._red_vals.data_ptr()),
-                                          int(eng._red_idx.data_ptr()), eng.stream), "qp_pauli_stats")
-        mx = float(eng._red_vals[0].item())
-        forb = int(eng._red_idx[1].item())
-        return mx, forb
+    def _guard_launch(self):
+        """Pauli guard over all members (device reduction + asynchronous read-back, as `run_2d_crank_nicolson` does)."""
+        return self.eng.pauli_stats_launch(self.state, self.tab, 1e-18, ncell=self.npix, flags=self.coll_flags)
+
+    def _guard_check(self, ticket):
+        mx, _, forb = self.eng.pauli_stats_result(ticket)
+        if forb is not None or mx > 1.0:
+            raise ValueError("Pauli guard tripped in the benchmark state")
+        self.max_occ = max(self.max_occ, mx)
 
     def run(self, k: int):
+        """k steps; the guard of step s is read on the host after step s+1 has been enqueued (every step is checked,
+        the last one before returning)."""
+        pending = None
         for _ in range(k):
             self._collide(0.5 * self.dt)
             self.eng.adi_steps(self.op, self.state, 1)
             self._collide(0.5 * self.dt)
-            mx, forb = self._guard()
-            if forb >= 0 or mx > 1.0:
-                raise ValueError("Pauli guard tripped in the benchmark state")
-            self.max_occ = max(self.max_occ, mx)
+            ticket = self._guard_launch()
+            if pending is not None:
+                self._guard_check(pending)
+            pending = ticket
+        if pending is not None:
+            self._guard_check(pending)
 
     def _pmc_traffic(self):
         """HBM bytes per collision call from the committed PMC summary of `--workload c3` (profiles/r01_c3_pmc.json)."""

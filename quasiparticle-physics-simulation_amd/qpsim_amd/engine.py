@@ -508,13 +508,37 @@ class Engine:
 
     def pauli_stats(self, state, tables, floor: float):
         """(max occupation, (energy index, cell index), forbidden (energy, cell) or None)."""
-        _hip.check(self.lib.qp_pauli_stats(_ptr(state), _ptr(tables["rho"]), _ptr(tables["cls"]), _ptr(self.d_flags),
-                                           tables["ne"], tables["nclass"], self.ncell, float(floor), _ptr(self._ws),
-                                           _ptr(self._red_vals), _ptr(self._red_idx), self.stream), "qp_pauli_stats")
-        mx = float(self._red_vals[0].item())
-        idx = self._red_idx.cpu().numpy()
-        top = (int(idx[0] // self.ncell), int(idx[0] % self.ncell))
-        forb = None if idx[1] < 0 else (int(idx[1] // self.ncell), int(idx[1] % self.ncell))
+        return self.pauli_stats_result(self.pauli_stats_launch(state, tables, floor))
+
+    def pauli_stats_launch(self, state, tables, floor: float, ncell: int | None = None, flags=None):
+        """Enqueue the Pauli-guard reduction and an asynchronous read-back into pinned memory; returns a ticket for
+        ``pauli_stats_result``.  Two tickets may be outstanding, so a time loop can enqueue the next step before it
+        looks at the previous step's guard and the GPU never waits for the host round trip."""
+        torch = self.torch
+        if not hasattr(self, "_guard_slots"):
+            self._guard_slots = [(torch.empty(2, dtype=torch.float64).pin_memory(),
+                                  torch.empty(2, dtype=torch.int64).pin_memory(),
+                                  torch.cuda.Event()) for _ in range(2)]
+            self._guard_next = 0
+        hv, hi, ev = self._guard_slots[self._guard_next]
+        self._guard_next ^= 1
+        nc = self.ncell if ncell is None else int(ncell)
+        _hip.check(self.lib.qp_pauli_stats(_ptr(state), _ptr(tables["rho"]), _ptr(tables["cls"]),
+                                           _ptr(self.d_flags if flags is None else flags), tables["ne"], tables["nclass"],
+                                           nc, float(floor), _ptr(self._ws), _ptr(self._red_vals), _ptr(self._red_idx),
+                                           self.stream), "qp_pauli_stats")
+        hv.copy_(self._red_vals, non_blocking=True)
+        hi.copy_(self._red_idx, non_blocking=True)
+        ev.record(torch.cuda.current_stream(self.device))
+        return hv, hi, ev, nc
+
+    def pauli_stats_result(self, ticket):
+        hv, hi, ev, nc = ticket
+        ev.synchronize()
+        mx = float(hv[0])
+        i0, i1 = int(hi[0]), int(hi[1])
+        top = (i0 // nc, i0 % nc)
+        forb = None if i1 < 0 else (i1 // nc, i1 % nc)
         return mx, top, forb
 
     def energy_integral(self, state, dE: float):

@@ -403,9 +403,24 @@ def run_2d_crank_nicolson(
     cell_to_px = np.cumsum(eng.mask_flat) - 1
     warned = False
 
-    def guard(step_idx: int, time_ns: float) -> None:            # Pauli guard (solver.py:1296-1344)
+    # The guard of step k is enqueued right after the step and examined after step k+1 has been enqueued (or before
+    # anything is stored / returned), so the device does not idle during the host round trip.  Messages carry the
+    # step / time of the step that was checked, exactly as the reference's.
+    pending_guard: list = []
+
+    def guard_launch(step_idx: int, time_ns: float) -> None:
+        pending_guard.append((eng.pauli_stats_launch(state, ctab, pauli_density_floor), step_idx, time_ns))
+
+    def guard_flush(keep: int = 0) -> None:
+        while len(pending_guard) > keep:
+            ticket, step_idx, time_ns = pending_guard.pop(0)
+            guard(step_idx, time_ns, eng.pauli_stats_result(ticket))
+
+    def guard(step_idx: int, time_ns: float, stats=None) -> None:   # Pauli guard (solver.py:1296-1344)
         nonlocal warned
-        max_occ, (ie_max, cell_max), forb = eng.pauli_stats(state, ctab, pauli_density_floor)
+        if stats is None:
+            stats = eng.pauli_stats(state, ctab, pauli_density_floor)
+        max_occ, (ie_max, cell_max), forb = stats
         if forb is not None:
             r, c = coords[cell_to_px[forb[1]]]
             msg = (f"Detected non-zero quasiparticle density in forbidden state (rho≈0): step={step_idx}, "
@@ -497,11 +512,13 @@ def run_2d_crank_nicolson(
             collide(dt_step)
             if enable_diffusion and dt_step > 0.0:
                 diffuser.step(state, final)
-        guard(step, current_time + dt_step)
+        guard_launch(step, current_time + dt_step)
+        guard_flush(keep=0 if stored(step) else 1)
         current_time += dt_step
         if stored(step):
             times.append(float(current_time))
             _notify(progress_callback, current_time, store())
+    guard_flush()
 
     limits = _color_limits(frames)
     if phonon_history_out is not None:
