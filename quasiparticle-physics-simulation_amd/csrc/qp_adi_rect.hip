@@ -38,6 +38,7 @@ struct RectDims {
   int gny, gnx;                 // global grid extent (== ny, nx without decomposition)
   int j0, i0;                   // global offset of the local block (multiples of 64)
   int gpy, gpx;                 // global chunks per column / per row
+  int stream;                   // non-temporal plane accesses (working set beyond the Infinity Cache)
 };
 
 struct RectView {
@@ -78,6 +79,7 @@ __device__ __forceinline__ TileCoord tile_coord(const RectDims& d) {
   t.i0 = t.tx * TS;
   t.nr = min(TS, d.ny - t.j0);
   t.nc = min(TS, d.nx - t.i0);
+  t.stream = d.stream;
   return t;
 }
 
@@ -423,7 +425,8 @@ int qp_adi_rect_plan_create_block(int32_t ny, int32_t nx, int32_t nfield, double
   plan->decomposed = decomposed;
   RectView& v = plan->view;
   v.d = RectDims{ny, nx, nfield, (ny + TS - 1) / TS, (nx + TS - 1) / TS, gny, gnx, j0, i0,
-                 (gny + TS - 1) / TS, (gnx + TS - 1) / TS};
+                 (gny + TS - 1) / TS, (gnx + TS - 1) / TS,
+                 (size_t)nfield * ny * nx * sizeof(double) > kStreamBytes ? 1 : 0};
   plan->ncell = (long)ny * nx;
   // bc_* order: left, right, up, down  (x-faces then y-faces); specs describe the GLOBAL lines
   DirSpec spec[2] = {{gnx, v.d.gpx, bc_diag[0], bc_diag[1], bc_src[0], bc_src[1]},

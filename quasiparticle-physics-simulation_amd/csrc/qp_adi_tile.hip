@@ -51,6 +51,7 @@ struct TileView {
   int ntiles[2];
   // variable-D plans (var != 0): per field, padded [pny][pnx] row-major (x) and [pnx][pny] column-major (y)
   int var;
+  int stream;                   // non-temporal plane accesses (working set beyond the Infinity Cache)
   const double* wx;             // weight of the face between (j, i) and (j, i+1)
   const double* wy;             // weight of the face between (j, i) and (j+1, i)
   const double* rdx;            // r D of the cell, row-major
@@ -264,6 +265,7 @@ __device__ __forceinline__ TileCoord tile_of(const TileView& v, bool& has_bc) {
   t.i0 = t.tx * TS;
   t.nr = min(TS, v.ny - t.j0);
   t.nc = min(TS, v.nx - t.i0);
+  t.stream = v.stream;
   return t;
 }
 
@@ -465,6 +467,7 @@ __global__ void __launch_bounds__(64) tile_setup_kernel(TileView v, int list, un
   t.i0 = t.tx * TS;
   t.nr = min(TS, v.ny - t.j0);
   t.nc = min(TS, v.nx - t.i0);
+  t.stream = 0;
   stage_bct(v, bct, lane);
   const double a = v.alpha[t.b];
   double far = 0.0;
@@ -638,6 +641,7 @@ static int tile_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, co
   v.ny = ny; v.nx = nx; v.nfield = nfield; v.py = py; v.px = px; v.pny = pny; v.pnx = pnx;
   v.nbc = (int)bc_index.size();
   v.var = var ? 1 : 0;
+  v.stream = (size_t)nfield * ny * nx * sizeof(double) > kStreamBytes ? 1 : 0;
   v.wx = v.wy = v.rdx = v.rdy = nullptr;
   plan->ncell = (long)ny * nx;
   plan->bct_bytes = bct.size() * sizeof(double);
