@@ -305,6 +305,7 @@ def run_2d_crank_nicolson(
         geom = CompiledGeometry(dev_mask, float(dx), link_flags(dev_mask), z, z, z, z)
     full_steps, rem, total_steps = _step_plan(total_time, dt)
     eng = Engine(geom, device=device)
+    eng.pin_stream()          # one stream for the whole run: skip the per-launch lookup
     stored = lambda step: step % store_every == 0 or step == total_steps  # noqa: E731
 
     if not energy_gap > 0.0:
