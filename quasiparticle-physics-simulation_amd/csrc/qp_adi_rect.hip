@@ -426,7 +426,7 @@ int qp_adi_rect_plan_create_block(int32_t ny, int32_t nx, int32_t nfield, double
   RectView& v = plan->view;
   v.d = RectDims{ny, nx, nfield, (ny + TS - 1) / TS, (nx + TS - 1) / TS, gny, gnx, j0, i0,
                  (gny + TS - 1) / TS, (gnx + TS - 1) / TS,
-                 (size_t)nfield * ny * nx * sizeof(double) > kStreamBytes ? 1 : 0};
+                 stream_mode((size_t)nfield * ny * nx * sizeof(double))};
   plan->ncell = (long)ny * nx;
   // bc_* order: left, right, up, down  (x-faces then y-faces); specs describe the GLOBAL lines
   DirSpec spec[2] = {{gnx, v.d.gpx, bc_diag[0], bc_diag[1], bc_src[0], bc_src[1]},

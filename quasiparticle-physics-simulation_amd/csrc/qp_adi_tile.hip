@@ -641,7 +641,7 @@ static int tile_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, co
   v.ny = ny; v.nx = nx; v.nfield = nfield; v.py = py; v.px = px; v.pny = pny; v.pnx = pnx;
   v.nbc = (int)bc_index.size();
   v.var = var ? 1 : 0;
-  v.stream = (size_t)nfield * ny * nx * sizeof(double) > kStreamBytes ? 1 : 0;
+  v.stream = stream_mode((size_t)nfield * ny * nx * sizeof(double));
   v.wx = v.wy = v.rdx = v.rdy = nullptr;
   plan->ncell = (long)ny * nx;
   plan->bct_bytes = bct.size() * sizeof(double);

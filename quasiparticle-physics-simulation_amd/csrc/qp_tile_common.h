@@ -2,6 +2,8 @@
 // One wave owns one 64 x 64 tile held as 64 doubles per lane.
 #pragma once
 
+#include <stdlib.h>
+
 #include "qp_common.h"
 
 namespace qp {
@@ -12,6 +14,14 @@ constexpr int TS = 64;          // tile edge = chunk length
 constexpr double kFarCouplingDrop = 1e-22;
 // carried plane sets above this size bypass the caches (see TileCoord::stream)
 constexpr size_t kStreamBytes = (size_t)192 << 20;
+// bit 0: non-temporal loads, bit 1: non-temporal stores; QPSIM_STREAM_MODE=0..3 overrides the size rule (tuning knob)
+inline int stream_mode(size_t plane_set_bytes) {
+  if (const char* e = getenv("QPSIM_STREAM_MODE")) return atoi(e) & 3;
+  // measured on MI355X (fraction of 8 TB/s, cached / NT stores / NT both): 4096^2 (128 MiB) 0.62 / 0.59 / 0.60;
+  // 8192^2 (512 MiB) 0.61 / 0.735 / 0.69; 16384^2 (2 GiB) 0.64 / 0.67 / 0.71
+  if (plane_set_bytes > 4 * kStreamBytes) return 3;
+  return plane_set_bytes > kStreamBytes ? 2 : 0;
+}
 
 // table slots per (direction, field, chunk variant); each slot is TS doubles
 enum { T_W = 0, T_AWF, T_AWB, T_CM, T_C0, T_CP, T_SRC, T_G, T_H, T_NSLOT };
@@ -117,7 +127,7 @@ __device__ __forceinline__ void load_cols(const double* __restrict__ base, const
   const double* p = base + (long)t.j0 * nx + t.i0;
   const unsigned l = (unsigned)lane;
   if (t.nr == TS && t.nc == TS) {      // interior tile (wave-uniform test): 64 unconditional row-segment loads
-    if (t.stream) {
+    if (t.stream & 1) {
       // the empty asm keeps the two branches distinct: without it the optimiser merges their (otherwise identical)
       // instructions and drops the non-temporal hint
       asm volatile("" ::: "memory");
@@ -140,7 +150,7 @@ __device__ __forceinline__ void store_cols(double* __restrict__ base, const Tile
   double* p = base + (long)t.j0 * nx + t.i0;
   const unsigned l = (unsigned)lane;
   if (t.nr == TS && t.nc == TS) {
-    if (t.stream) {
+    if (t.stream & 2) {
       asm volatile("" ::: "memory");
 #pragma unroll
       for (int r = 0; r < TS; ++r) __builtin_nontemporal_store(v[r], &(p + (long)r * nx)[l]);
