@@ -107,11 +107,15 @@ typedef struct qp_collision_tables {
   const int32_t* cls;      /* [ncell] gap class per cell, or NULL when nclass == 1 */
   /* Optional structure hint (both or neither).  On the reference's uniform energy grid idx_diff[i][j] = diag_bin[|i-j|]
    * and idx_sum[i][j] = anti_bin[i+j], sign[i][j] = sign(i-j); pass the two arrays when the host has verified that.
-   * If a phonon bin is shared between a diagonal and an anti-diagonal (merged bins) also set QP_COLL_SHARED_BINS:
-   * the register-resident kernel (nclass == 1, ne <= 16) needs unshared bins, the one-wave-per-pixel kernel does not. */
+   * If a phonon bin is shared between a diagonal k and an anti-diagonal m (merged bins, e.g. whenever 2 E_min / dE is an
+   * integer) also set QP_COLL_SHARED_BINS and tag BOTH entries, diag_bin[k] and anti_bin[m], with (slot + 1) << 16 on top of
+   * the bin index (slot = 0, 1, ... numbering the merged bins): the register-resident kernels then park the diagonal's sums
+   * in ph_scratch[2 slot], ph_scratch[2 slot + 1] (planes of ncell doubles) until the anti-diagonal finalises the bin, so
+   * ph_scratch must hold 2 * (number of merged bins) * ncell doubles when phonons are updated with both processes on. */
   const int32_t* diag_bin; /* [ne] or NULL */
   const int32_t* anti_bin; /* [2*ne-1] or NULL */
-  /* Kernel selection.  Default (0): register-resident kernel when (diag_bin, nclass == 1, ne <= 16); otherwise, for
+  /* Kernel selection.  Default (0): register-resident kernel when (diag_bin, nclass == 1,
+   * qp_collision_register_kernel_available(ne)); otherwise, for
    * ne <= 64, one wave per pixel with lanes <-> energy bins (deterministic when diag_bin vouches for the bin-map structure,
    * LDS atomics otherwise); otherwise the generic one-thread-per-cell kernel.  The FORCE bits exist for tests. */
   uint32_t flags;

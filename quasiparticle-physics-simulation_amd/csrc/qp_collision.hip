@@ -127,8 +127,9 @@ __global__ void __launch_bounds__(256) collision_generic_kernel(CollView t, cons
 }
 
 bool collision_fast_dispatch(int ne, const double* kr0, const double* ks0, const double* rho, const int* diag_bin,
-                             const int* anti_bin, const uint8_t* flags, long ncell, const double* sin_, double* sout,
-                             double* ph, double dE, double dt, int en_r, int en_s, int upd, hipStream_t stream);
+                             const int* anti_bin, double* stash, const uint8_t* flags, long ncell, const double* sin_,
+                             double* sout, double* ph, double dE, double dt, int en_r, int en_s, int upd,
+                             hipStream_t stream);
 
 int collision_fast_supported(int ne);
 
@@ -165,10 +166,14 @@ extern "C" int qp_collision_step(const qp_collision_tables* t, const uint8_t* fl
   QP_REQUIRE(!(update_phonons && (enable_recombination || enable_scattering)) || ph_scratch || no_scratch_ok,
              "ph_scratch is required when phonons are updated by the generic kernel");
   QP_REQUIRE((t->diag_bin == nullptr) == (t->anti_bin == nullptr), "diag_bin and anti_bin come together");
-  if (t->diag_bin && t->nclass == 1 && !(t->flags & (QP_COLL_FORCE_GENERIC | QP_COLL_FORCE_WAVE | QP_COLL_SHARED_BINS)) &&
-      qp::collision_fast_dispatch(t->ne, t->kr0, t->ks0, t->rho, t->diag_bin, t->anti_bin, flags, (long)ncell, state_in,
-                                  state_out, phonon, dE, dt, enable_recombination, enable_scattering, update_phonons,
-                                  (hipStream_t)stream))
+  // merged bins (QP_COLL_SHARED_BINS): the register kernels park per-diagonal sums in ph_scratch (2 planes per merged bin);
+  // without scratch only the variants that never write phonons qualify
+  const bool shared_ok = !(t->flags & QP_COLL_SHARED_BINS) || ph_scratch ||
+                         !(update_phonons && enable_recombination && enable_scattering && t->kr0 && t->ks0);
+  if (t->diag_bin && t->nclass == 1 && !(t->flags & (QP_COLL_FORCE_GENERIC | QP_COLL_FORCE_WAVE)) && shared_ok &&
+      qp::collision_fast_dispatch(t->ne, t->kr0, t->ks0, t->rho, t->diag_bin, t->anti_bin, ph_scratch, flags, (long)ncell,
+                                  state_in, state_out, phonon, dE, dt, enable_recombination, enable_scattering,
+                                  update_phonons, (hipStream_t)stream))
     return qp::check_launch("qp_collision_step(fast)");
   // NE <= 64: one wave per pixel (any class map; LDS atomics unless the host vouched for the bin-map structure)
   if (!(t->flags & QP_COLL_FORCE_GENERIC)) {

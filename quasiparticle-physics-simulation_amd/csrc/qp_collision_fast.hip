@@ -20,10 +20,11 @@ __global__ void __launch_bounds__(256) collision_none_kernel(const uint8_t* __re
 
 // returns false when NE has no instantiation or the cell count exceeds the 32-bit offset range
 bool collision_fast_dispatch(int ne, const double* kr0, const double* ks0, const double* rho, const int* diag_bin,
-                             const int* anti_bin, const uint8_t* flags, long ncell, const double* sin_, double* sout,
-                             double* ph, double dE, double dt, int en_r, int en_s, int upd, hipStream_t stream) {
+                             const int* anti_bin, double* stash, const uint8_t* flags, long ncell, const double* sin_,
+                             double* sout, double* ph, double dE, double dt, int en_r, int en_s, int upd,
+                             hipStream_t stream) {
   if (ncell >= (1L << 28)) return false;
-  CollFastView v{kr0, ks0, rho, diag_bin, anti_bin};
+  CollFastView v{kr0, ks0, rho, diag_bin, anti_bin, stash};
   const bool s = en_s && ks0, r = en_r && kr0, u = upd && (s || r);
   diag_launcher_t fn = nullptr;
   switch (ne) {

@@ -172,6 +172,8 @@ class CoupledWorkload:
         acc = None
         if self.upd and not self.tab["fast"]:
             acc = eng.scratch("coll_acc", 2 * self.tab["nw"] * self.npix)
+        elif self.upd and self.tab["merged_slots"] and self.en_r and self.en_s:
+            acc = eng.scratch("coll_acc", 2 * self.tab["merged_slots"] * self.npix)
         _hip.check(eng.lib.qp_collision_step(C.byref(self.tab["struct"]), int(self.coll_flags.data_ptr()), self.npix,
                                              int(self.state.data_ptr()), int(self.alt.data_ptr()),
                                              int(self.phonon.data_ptr()), 0 if acc is None else int(acc.data_ptr()),

@@ -500,10 +500,23 @@ class Engine:
             h["cls"] = up(full, np.int32)
         h["nw"] = nw
         h["diag_bin"] = h["anti_bin"] = None
+        h["merged_slots"] = 0
         structure = structured_bin_maps(idx_diff, idx_sum, sign, allow_shared=True)
         shared = structure is not None and structured_bin_maps(idx_diff, idx_sum, sign) is None
         if structure is not None and kernel != "wave_unstructured":
-            h["diag_bin"], h["anti_bin"] = up(structure[0], np.int32), up(structure[1], np.int32)
+            diag, anti = (np.array(a, dtype=np.int32) for a in structure)
+            if shared:
+                # a phonon bin fed by diagonal k AND anti-diagonal m: both table entries carry (slot + 1) << 16 so that the
+                # register kernels park the diagonal's sums in scratch slot `slot` until the anti-diagonal finalises the bin
+                where = {int(b): m for m, b in enumerate(anti)}
+                for k in range(1, ne):
+                    m = where.get(int(diag[k]))
+                    if m is not None:
+                        tag = (h["merged_slots"] + 1) << 16
+                        diag[k] |= tag
+                        anti[m] |= tag
+                        h["merged_slots"] += 1
+            h["diag_bin"], h["anti_bin"] = up(diag, np.int32), up(anti, np.int32)
         if not allow_fast and kernel == "auto":
             kernel = "generic"
         flag_bits = {"auto": 0, "generic": 1, "wave": 2, "wave_unstructured": 2}[kernel] | (4 if shared else 0)
@@ -511,7 +524,7 @@ class Engine:
             kernel = "wave"
         wave_ok = ne <= 64 and nw <= 192
         h["kernel"] = ("generic" if (kernel == "generic" or not wave_ok) else
-                       "register" if (kernel == "auto" and structure is not None and not shared and nclass == 1
+                       "register" if (kernel == "auto" and structure is not None and nclass == 1
                                       and bool(self.lib.qp_collision_register_kernel_available(ne))) else "wave")
         h["fast"] = h["kernel"] != "generic"      # no accumulator planes needed
         h["struct"] = _hip.CollisionTables(ne, nw, nclass, _ptr(h["kr0"]), _ptr(h["ks0"]), _ptr(h["rho"]),
@@ -522,6 +535,8 @@ class Engine:
     def collide(self, tables, state, state_out, phonon, dE, dt, en_r, en_s, update_phonons):
         need_acc = update_phonons and (en_r or en_s) and not tables["fast"]
         acc = self.scratch("coll_acc", 2 * tables["nw"] * self.ncell) if need_acc else None
+        if tables["kernel"] == "register" and tables["merged_slots"] and update_phonons and en_r and en_s:
+            acc = self.scratch("coll_acc", 2 * tables["merged_slots"] * self.ncell)      # merged-bin stash
         _hip.check(self.lib.qp_collision_step(C.byref(tables["struct"]), _ptr(self.d_flags), self.ncell, _ptr(state),
                                               _ptr(state_out), _ptr(phonon), _ptr(acc), float(dE), float(dt),
                                               int(bool(en_r)), int(bool(en_s)), int(bool(update_phonons)), self.stream),
