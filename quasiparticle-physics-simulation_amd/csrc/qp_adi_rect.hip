@@ -68,6 +68,9 @@ __device__ __forceinline__ ctab_t table_ptr(const RectView& v, int dir, int b, i
   return as_const(v.tab + ((((long)dir * v.d.nfield + b) * 4 + variant) * T_NSLOT) * TS);
 }
 
+// STREAM is a template parameter of the kernels: the headline configuration (cached accesses) keeps exactly the code it
+// had before the non-temporal variants existed (a run-time branch cost ~3 % there)
+template <int STREAM>
 __device__ __forceinline__ TileCoord tile_coord(const RectDims& d) {
   TileCoord t;
   int id = blockIdx.x;
@@ -79,7 +82,7 @@ __device__ __forceinline__ TileCoord tile_coord(const RectDims& d) {
   t.i0 = t.tx * TS;
   t.nr = min(TS, d.ny - t.j0);
   t.nc = min(TS, d.nx - t.i0);
-  t.stream = d.stream;
+  t.stream = STREAM;
   return t;
 }
 
@@ -125,11 +128,11 @@ __device__ __forceinline__ void chunk_ghosts(const RectView& v, int b, int p, lo
 // x-kernel: finish the x-solve, apply the explicit x-operator, eliminate along y.   buf: rhs1 -> rhs2 in place
 // ---------------------------------------------------------------------------------------------------------
 // EXPLICIT = false is the plain solve (I - a Lx)^-1 used by the exact-CN preconditioner: no explicit operator, no sources.
-template <bool EXPLICIT>
+template <bool EXPLICIT, int STREAM>
 __global__ void __launch_bounds__(64) rect_x_kernel(RectView v, double* __restrict__ buf) {
   __shared__ double lds[LDS_DOUBLES];
   const int lane = threadIdx.x;
-  const TileCoord t = tile_coord(v.d);
+  const TileCoord t = tile_coord<STREAM>(v.d);
   const long ncell = (long)v.d.ny * v.d.nx;
   double* plane = buf + (long)t.b * ncell;
   const double a = as_const(v.alpha)[t.b];
@@ -167,11 +170,11 @@ __global__ void __launch_bounds__(64) rect_x_kernel(RectView v, double* __restri
 //            MODE 2 (exit):  src = rhs2, y-solve, dst = u'
 //            MODE 3 (reduce): src = rhs of an x-solve; only its reduced right-hand sides are formed (nothing stored)
 // ---------------------------------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, int STREAM>
 __global__ void __launch_bounds__(64) rect_y_kernel(RectView v, const double* src, double* dst) {  // src may alias dst
   __shared__ double lds[LDS_DOUBLES];
   const int lane = threadIdx.x;
-  const TileCoord t = tile_coord(v.d);
+  const TileCoord t = tile_coord<STREAM>(v.d);
   const long ncell = (long)v.d.ny * v.d.nx;
   const double* splane = src + (long)t.b * ncell;
   double* dplane = dst + (long)t.b * ncell;
@@ -373,6 +376,14 @@ static double reduced_tables(const DirSpec& s, double a, int p0, int Ploc, doubl
 
 }  // namespace qp
 
+// launches NAME<ARG, STREAM> for the plan's stream mode (0 cached, 2 non-temporal stores, 3 non-temporal both)
+#define QP_LAUNCH_STREAMED(mode, NAME, ARG, ...)                                   \
+  do {                                                                             \
+    if ((mode) == 0) hipLaunchKernelGGL((NAME<ARG, 0>), __VA_ARGS__);              \
+    else if ((mode) == 2) hipLaunchKernelGGL((NAME<ARG, 2>), __VA_ARGS__);         \
+    else hipLaunchKernelGGL((NAME<ARG, 3>), __VA_ARGS__);                          \
+  } while (0)
+
 struct qp_adi_rect_plan {
   qp::RectView view;
   double* d_alpha = nullptr;
@@ -531,7 +542,7 @@ int qp_adi_rect_phase(qp_adi_rect_plan* plan, int32_t phase, double* u, void* st
   switch (phase) {
     case QP_ADI_ENTRY:
       QP_REQUIRE(u != nullptr, "u is NULL");
-      hipLaunchKernelGGL(rect_y_kernel<0>, dim3(tiles), dim3(64), 0, stream, v, (const double*)u, w);
+      QP_LAUNCH_STREAMED(v.d.stream, rect_y_kernel, 0, dim3(tiles), dim3(64), 0, stream, v, (const double*)u, w);
       break;
     case QP_ADI_REDUCED_X:
       if (!v.decoupled[0])
@@ -539,7 +550,7 @@ int qp_adi_rect_phase(qp_adi_rect_plan* plan, int32_t phase, double* u, void* st
                            stream, v, 0);
       break;
     case QP_ADI_SWEEP_X:
-      hipLaunchKernelGGL(rect_x_kernel<true>, dim3(tiles), dim3(64), 0, stream, v, w);
+      QP_LAUNCH_STREAMED(v.d.stream, rect_x_kernel, true, dim3(tiles), dim3(64), 0, stream, v, w);
       break;
     case QP_ADI_REDUCED_Y:
       if (!v.decoupled[1])
@@ -547,11 +558,11 @@ int qp_adi_rect_phase(qp_adi_rect_plan* plan, int32_t phase, double* u, void* st
                            stream, v, 1);
       break;
     case QP_ADI_SWEEP_Y_CARRY:
-      hipLaunchKernelGGL(rect_y_kernel<1>, dim3(tiles), dim3(64), 0, stream, v, (const double*)w, w);
+      QP_LAUNCH_STREAMED(v.d.stream, rect_y_kernel, 1, dim3(tiles), dim3(64), 0, stream, v, (const double*)w, w);
       break;
     case QP_ADI_SWEEP_Y_EXIT:
       QP_REQUIRE(u != nullptr, "u is NULL");
-      hipLaunchKernelGGL(rect_y_kernel<2>, dim3(tiles), dim3(64), 0, stream, v, (const double*)w, u);
+      QP_LAUNCH_STREAMED(v.d.stream, rect_y_kernel, 2, dim3(tiles), dim3(64), 0, stream, v, (const double*)w, u);
       break;
     default:
       set_error("qp_adi_rect_phase: unknown phase %d", phase);
@@ -583,13 +594,13 @@ int qp_adi_rect_solve(qp_adi_rect_plan* plan, double* x, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   const RectView& v = plan->view;
   const unsigned tiles = (unsigned)((long)v.d.nfield * v.d.py * v.d.px);
-  hipLaunchKernelGGL(rect_y_kernel<3>, dim3(tiles), dim3(64), 0, stream, v, (const double*)x, x);
+  QP_LAUNCH_STREAMED(v.d.stream, rect_y_kernel, 3, dim3(tiles), dim3(64), 0, stream, v, (const double*)x, x);
   int rc = qp_adi_rect_phase(plan, QP_ADI_REDUCED_X, x, stream_);
   if (rc) return rc;
-  hipLaunchKernelGGL(rect_x_kernel<false>, dim3(tiles), dim3(64), 0, stream, v, x);
+  QP_LAUNCH_STREAMED(v.d.stream, rect_x_kernel, false, dim3(tiles), dim3(64), 0, stream, v, x);
   rc = qp_adi_rect_phase(plan, QP_ADI_REDUCED_Y, x, stream_);
   if (rc) return rc;
-  hipLaunchKernelGGL(rect_y_kernel<2>, dim3(tiles), dim3(64), 0, stream, v, (const double*)x, x);
+  QP_LAUNCH_STREAMED(v.d.stream, rect_y_kernel, 2, dim3(tiles), dim3(64), 0, stream, v, (const double*)x, x);
   return check_launch("qp_adi_rect_solve");
 }
 

@@ -20,7 +20,7 @@ inline int stream_mode(size_t plane_set_bytes) {
   // measured on MI355X (fraction of 8 TB/s, cached / NT stores / NT both): 4096^2 (128 MiB) 0.62 / 0.59 / 0.60;
   // 8192^2 (512 MiB) 0.61 / 0.735 / 0.69; 16384^2 (2 GiB) 0.64 / 0.67 / 0.71
   if (plane_set_bytes > 4 * kStreamBytes) return 3;
-  return plane_set_bytes > kStreamBytes ? 2 : 0;
+  return plane_set_bytes > kStreamBytes ? 2 : 0;      // (an environment override of 1 is served by the kernels of 3)
 }
 
 // table slots per (direction, field, chunk variant); each slot is TS doubles
