@@ -251,7 +251,9 @@ __device__ __forceinline__ void tile_ghosts(const TileView& v, int b, int p, lon
 constexpr int kTileHasBc = 1 << 30;      // tile-list entry: (has_bc << 30) | (ty << 16) | tx
 
 // CLS 0: clean tile, 1: general tile with uniform D, 2: tile of a variable-D plan
-template <int CLS>
+// STREAM >= 0: stream mode known at compile time (clean tiles: the bandwidth-bound kernels keep branch-free accesses);
+// STREAM < 0: taken from the plan at run time (general tiles are issue-bound, one variant suffices)
+template <int CLS, int STREAM>
 __device__ __forceinline__ TileCoord tile_of(const TileView& v, bool& has_bc) {
   TileCoord t;
   const int id = blockIdx.x;
@@ -265,7 +267,7 @@ __device__ __forceinline__ TileCoord tile_of(const TileView& v, bool& has_bc) {
   t.i0 = t.tx * TS;
   t.nr = min(TS, v.ny - t.j0);
   t.nc = min(TS, v.nx - t.i0);
-  t.stream = v.stream;
+  t.stream = STREAM >= 0 ? STREAM : v.stream;
   return t;
 }
 
@@ -352,13 +354,13 @@ __device__ __forceinline__ void line_ends(const TileView& v, const TileCoord& t,
 }
 
 // x-kernel: finish the x-solve, [apply (I + a Lx) . + a S], store, chunk-local eliminations along y -> iface[1]
-template <int CLS, bool EXPLICIT>
+template <int CLS, bool EXPLICIT, int STREAM>
 __global__ void __launch_bounds__(64) tile_x_kernel(TileView v, double* __restrict__ buf) {
   __shared__ double lds[LDS_DOUBLES];
   extern __shared__ double bct[];
   const int lane = threadIdx.x;
   bool has_bc;
-  const TileCoord t = tile_of<CLS>(v, has_bc);
+  const TileCoord t = tile_of<CLS, STREAM>(v, has_bc);
   if (CLS != 0) stage_bct(v, bct, lane);
   const long ncell = (long)v.ny * v.nx;
   double* plane = buf + (long)t.b * ncell;
@@ -396,13 +398,13 @@ __global__ void __launch_bounds__(64) tile_x_kernel(TileView v, double* __restri
 // y-kernel.  MODE 0 (entry): src = u -> rhs1 = (I + a Ly) u + a S;  MODE 1 (carry): y-solve, rhs1' of the next step;
 //            MODE 2 (exit): y-solve, dst = u';  MODE 3 (reduce): only the x-eliminations of src (nothing stored).
 //            MODE 0, 1, 3 end with the chunk-local eliminations along x -> iface[0]
-template <int CLS, int MODE>
+template <int CLS, int MODE, int STREAM>
 __global__ void __launch_bounds__(64) tile_y_kernel(TileView v, const double* src, double* dst) {   // src may alias dst
   __shared__ double lds[LDS_DOUBLES];
   extern __shared__ double bct[];
   const int lane = threadIdx.x;
   bool has_bc;
-  const TileCoord t = tile_of<CLS>(v, has_bc);
+  const TileCoord t = tile_of<CLS, STREAM>(v, has_bc);
   if (CLS != 0) stage_bct(v, bct, lane);
   const long ncell = (long)v.ny * v.nx;
   const double* splane = src + (long)t.b * ncell;
@@ -752,28 +754,34 @@ namespace qp {
 template <bool EXPLICIT>
 static void launch_x(const qp_adi_tile_plan* plan, double* buf, hipStream_t stream) {
   const TileView& v = plan->view;
-  if (v.ntiles[0] > 0)
-    hipLaunchKernelGGL((tile_x_kernel<0, EXPLICIT>), dim3((unsigned)((long)v.ntiles[0] * v.nfield)), dim3(64), 0, stream,
-                       v, buf);
+  if (v.ntiles[0] > 0) {
+    const dim3 grid((unsigned)((long)v.ntiles[0] * v.nfield));
+    if (v.stream == 0) hipLaunchKernelGGL((tile_x_kernel<0, EXPLICIT, 0>), grid, dim3(64), 0, stream, v, buf);
+    else if (v.stream == 2) hipLaunchKernelGGL((tile_x_kernel<0, EXPLICIT, 2>), grid, dim3(64), 0, stream, v, buf);
+    else hipLaunchKernelGGL((tile_x_kernel<0, EXPLICIT, 3>), grid, dim3(64), 0, stream, v, buf);
+  }
   if (v.ntiles[1] > 0 && !v.var)
-    hipLaunchKernelGGL((tile_x_kernel<1, EXPLICIT>), dim3((unsigned)((long)v.ntiles[1] * v.nfield)), dim3(64),
+    hipLaunchKernelGGL((tile_x_kernel<1, EXPLICIT, -1>), dim3((unsigned)((long)v.ntiles[1] * v.nfield)), dim3(64),
                        plan->bct_bytes, stream, v, buf);
   if (v.ntiles[1] > 0 && v.var)
-    hipLaunchKernelGGL((tile_x_kernel<2, EXPLICIT>), dim3((unsigned)((long)v.ntiles[1] * v.nfield)), dim3(64),
+    hipLaunchKernelGGL((tile_x_kernel<2, EXPLICIT, -1>), dim3((unsigned)((long)v.ntiles[1] * v.nfield)), dim3(64),
                        plan->bct_bytes, stream, v, buf);
 }
 
 template <int MODE>
 static void launch_y(const qp_adi_tile_plan* plan, const double* src, double* dst, hipStream_t stream) {
   const TileView& v = plan->view;
-  if (v.ntiles[0] > 0)
-    hipLaunchKernelGGL((tile_y_kernel<0, MODE>), dim3((unsigned)((long)v.ntiles[0] * v.nfield)), dim3(64), 0, stream, v,
-                       src, dst);
+  if (v.ntiles[0] > 0) {
+    const dim3 grid((unsigned)((long)v.ntiles[0] * v.nfield));
+    if (v.stream == 0) hipLaunchKernelGGL((tile_y_kernel<0, MODE, 0>), grid, dim3(64), 0, stream, v, src, dst);
+    else if (v.stream == 2) hipLaunchKernelGGL((tile_y_kernel<0, MODE, 2>), grid, dim3(64), 0, stream, v, src, dst);
+    else hipLaunchKernelGGL((tile_y_kernel<0, MODE, 3>), grid, dim3(64), 0, stream, v, src, dst);
+  }
   if (v.ntiles[1] > 0 && !v.var)
-    hipLaunchKernelGGL((tile_y_kernel<1, MODE>), dim3((unsigned)((long)v.ntiles[1] * v.nfield)), dim3(64),
+    hipLaunchKernelGGL((tile_y_kernel<1, MODE, -1>), dim3((unsigned)((long)v.ntiles[1] * v.nfield)), dim3(64),
                        plan->bct_bytes, stream, v, src, dst);
   if (v.ntiles[1] > 0 && v.var)
-    hipLaunchKernelGGL((tile_y_kernel<2, MODE>), dim3((unsigned)((long)v.ntiles[1] * v.nfield)), dim3(64),
+    hipLaunchKernelGGL((tile_y_kernel<2, MODE, -1>), dim3((unsigned)((long)v.ntiles[1] * v.nfield)), dim3(64),
                        plan->bct_bytes, stream, v, src, dst);
 }
 
