@@ -374,14 +374,22 @@ class Engine:
             self._interior_idx = self.torch.as_tensor(np.flatnonzero(self.mask_flat), device=self.device)
         return self._interior_idx
 
-    def download_frames(self, planes, scale: float = 1.0) -> np.ndarray:
+    def download_frames(self, planes, scale: float = 1.0, full_shape=None, offset=(0, 0)) -> np.ndarray:
         """[nfield, ncell] device planes -> host [nfield, ny, nx] frames, NaN outside the mask (reconstruct_field), times
-        `scale`; the padding happens on the device, the host only receives."""
+        `scale`; the padding happens on the device, the host only receives.  With ``full_shape`` the engine grid is the
+        window at ``offset`` of a larger all-NaN frame (the solver crops padded geometries onto their bounding box)."""
+        torch = self.torch
         planes = planes.reshape(-1, self.ncell)
-        out = self.empty(planes.shape[0], self.ncell)
-        _hip.check(self.lib.qp_nan_pad(_ptr(self.d_flags), self.ncell, planes.shape[0], _ptr(planes), float(scale),
-                                       _ptr(out), self.stream), "qp_nan_pad")
-        return out.cpu().numpy().reshape(planes.shape[0], self.ny, self.nx)
+        n = planes.shape[0]
+        out = self.empty(n, self.ncell)
+        _hip.check(self.lib.qp_nan_pad(_ptr(self.d_flags), self.ncell, n, _ptr(planes), float(scale), _ptr(out),
+                                       self.stream), "qp_nan_pad")
+        out = out.view(n, self.ny, self.nx)
+        if full_shape is not None and tuple(full_shape) != (self.ny, self.nx):
+            full = torch.full((n,) + tuple(full_shape), float("nan"), dtype=torch.float64, device=self.device)
+            full[:, offset[0]:offset[0] + self.ny, offset[1]:offset[1] + self.nx] = out
+            out = full
+        return out.cpu().numpy()
 
     def masked_sum(self, plane) -> float:
         """Sum of one plane over the cells inside the mask (holes hold 0 by invariant)."""

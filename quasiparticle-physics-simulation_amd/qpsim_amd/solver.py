@@ -163,15 +163,12 @@ def _crop_to_bounding_box(mask: np.ndarray, edges: list[EdgeSegment]):
 
 def _device_frames(eng, planes, mask: np.ndarray) -> np.ndarray:
     """Device planes -> host [n, ny, nx] frames on the FULL mask, NaN outside the interior (reconstruct_field semantics).
-    The padding is done on the device for the engine's grid; a cropped engine grid is embedded into the full frame."""
-    fr = eng.download_frames(planes)
-    if fr.shape[1:] == mask.shape:
-        return fr
+    Padding and, for a cropped engine grid, the embedding into the full frame are done on the device."""
+    if (eng.ny, eng.nx) == mask.shape:
+        return eng.download_frames(planes)
     r0 = int(np.flatnonzero(mask.any(axis=1))[0])
     c0 = int(np.flatnonzero(mask.any(axis=0))[0])
-    out = np.full((fr.shape[0],) + mask.shape, np.nan)
-    out[:, r0:r0 + fr.shape[1], c0:c0 + fr.shape[2]] = fr
-    return out
+    return eng.download_frames(planes, full_shape=mask.shape, offset=(r0, c0))
 
 
 def _step_plan(total_time: float, dt: float) -> tuple[int, float, int]:
