@@ -2,7 +2,7 @@
 // Larger NE live in qp_collision_fast_u*.hip; every NE listed in QP_DIAG_NE_LIST has all process combinations.
 #include "qp_collision_fast.inc"
 
-#define QP_DIAG_NE_LIST(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(28) X(30) X(32) X(36) X(40) X(45) X(50)
+#define QP_DIAG_NE_LIST(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(18) X(20) X(24) X(30) X(32) X(40) X(50)
 
 namespace qp {
 

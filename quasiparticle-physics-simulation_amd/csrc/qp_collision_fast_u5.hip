@@ -1,7 +1,6 @@
-// Register collision kernels, NE = 32, 36 (see qp_collision_fast.inc).
+// Register collision kernels, NE = 40 (see qp_collision_fast.inc).
 #include "qp_collision_fast.inc"
 
 namespace qp {
-QP_DEFINE_DIAG(32)
-QP_DEFINE_DIAG(36)
+QP_DEFINE_DIAG(40)
 }  // namespace qp
