@@ -219,6 +219,28 @@ class _Diffuser:
             self.iterations += self.eng.cn_exact_step(op, u, rtol=self.rtol)
 
 
+def _on_run_device(fn):
+    """Runs ``fn`` with the HIP device of its ``device=`` argument current in the calling thread (kernel launches through
+    the C ABI go to the thread's current device; the reference's GUI calls the solver from a worker thread)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        try:
+            import torch
+            usable = torch.cuda.is_available()
+        except Exception:            # no torch / no GPU: let the body raise its own error after argument validation
+            usable = False
+        if not usable:
+            return fn(*args, **kwargs)
+        dev = kwargs.get("device")
+        dev = torch.device("cuda", torch.cuda.current_device()) if dev is None else torch.device(dev)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return wrapper
+
+
+@_on_run_device
 def run_2d_crank_nicolson(
     mask: np.ndarray,
     edges: list[EdgeSegment],

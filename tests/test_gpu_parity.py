@@ -874,3 +874,32 @@ def test_tile_path_variable_diffusivity_matches_oracle_and_per_line_kernels(O, k
         Dg[mask] = Dp[k]
         assert rel_err(got[k], O.CNStepper(ops, Dg, dt).step(u0[k])) < 1e-11
     assert its < 200
+
+
+def test_solver_runs_from_a_worker_thread_like_the_gui():
+    """ui/main_app.py:1937-1968 calls the solver from a daemon thread with a progress callback: same result as on the main
+    thread, callback invoked at t = 0 and at every stored step on that worker thread."""
+    import threading
+    from qpsim_amd.geometry import extract_edge_segments
+    from qpsim_amd.models import BoundaryCondition
+    from qpsim_amd.solver import run_2d_crank_nicolson
+    mask = _donut(40, 48, 18.0, 6.0)
+    edges = extract_edge_segments(mask)
+    bcs = {e.edge_id: BoundaryCondition("reflective") for e in edges}
+    init = np.where(mask, 1e-4 * (1 + np.random.default_rng(2).random(mask.shape)), 0.0)
+    kw = dict(mask=mask, edges=edges, edge_conditions=bcs, initial_field=init, diffusion_coefficient=6.0, dt=0.1,
+              total_time=1.0, dx=1.0, store_every=5, energy_gap=180.0, energy_max_factor=3.0, num_energy_bins=8,
+              enable_recombination=True, enable_scattering=True)
+    ref = run_2d_crank_nicolson(**kw)
+    seen, box = [], {}
+
+    def work():
+        box["out"] = run_2d_crank_nicolson(**kw, progress_callback=lambda t, f: seen.append((t, threading.get_ident())))
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(120)
+    assert not th.is_alive() and "out" in box
+    assert [t for t, _ in seen] == pytest.approx(ref[0]) and {tid for _, tid in seen} == {th.ident}
+    assert np.array_equal(np.stack(box["out"][1]), np.stack(ref[1]), equal_nan=True)
+    assert box["out"][2] == ref[2]
