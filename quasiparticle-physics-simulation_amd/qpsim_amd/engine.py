@@ -195,6 +195,22 @@ def structured_bin_maps(idx_diff, idx_sum, sign, allow_shared: bool = False):
     return diag.astype(np.int32), anti.astype(np.int32)
 
 
+def tag_merged_bins(diag, anti):
+    """(diag, anti, n_merged): entries of a phonon bin fed by both a diagonal k >= 1 and an anti-diagonal m get
+    (slot + 1) << 16 added, slot numbering the merged bins (what the register collision kernels expect, qpsim_hip.h)."""
+    diag, anti = np.array(diag, dtype=np.int32), np.array(anti, dtype=np.int32)
+    where = {int(b): m for m, b in enumerate(anti)}
+    slots = 0
+    for k in range(1, diag.size):
+        m = where.get(int(diag[k]))
+        if m is not None:
+            tag = (slots + 1) << 16
+            diag[k] |= tag
+            anti[m] |= tag
+            slots += 1
+    return diag, anti, slots
+
+
 class RectPlan:
     """Owner of a ``qp_adi_rect_plan`` (device tables + work planes of the fast full-rectangle ADI path)."""
 
@@ -516,14 +532,7 @@ class Engine:
             if shared:
                 # a phonon bin fed by diagonal k AND anti-diagonal m: both table entries carry (slot + 1) << 16 so that the
                 # register kernels park the diagonal's sums in scratch slot `slot` until the anti-diagonal finalises the bin
-                where = {int(b): m for m, b in enumerate(anti)}
-                for k in range(1, ne):
-                    m = where.get(int(diag[k]))
-                    if m is not None:
-                        tag = (h["merged_slots"] + 1) << 16
-                        diag[k] |= tag
-                        anti[m] |= tag
-                        h["merged_slots"] += 1
+                diag, anti, h["merged_slots"] = tag_merged_bins(diag, anti)
             h["diag_bin"], h["anti_bin"] = up(diag, np.int32), up(anti, np.int32)
         if not allow_fast and kernel == "auto":
             kernel = "generic"

@@ -175,3 +175,22 @@ def test_canonicalize_initial_condition_fills_defaults():
     assert c.spatial_params == {"amplitude": 1.0, "x0": 0.5, "y0": 0.5, "sigma": 0.12} and c.phonon_spatial_params == {"value": 1.0}
     d = ic.canonicalize_initial_condition(InitialConditionSpec(spatial_kind=" Uniform ", spatial_params={"value": 2.0}))
     assert d.spatial_kind == "uniform" and d.spatial_params == {"value": 2.0}
+
+
+def test_merged_bin_tagging_pairs_each_shared_bin_once():
+    """Slot tags of merged phonon bins (register collision kernels): every bin shared by a diagonal and an anti-diagonal
+    gets the same tag on both entries, tags are 1..n, untagged entries keep their bin."""
+    from qpsim_amd import tables as T
+    from qpsim_amd.engine import structured_bin_maps, tag_merged_bins
+    for ne, fmax in ((12, 5.0), (18, 10.0), (50, 5.0), (12, 3.0)):
+        E, _ = T.build_energy_grid(180.0, 1.0, fmax, ne)
+        om, idx_d, idx_s, sg = T.build_phonon_frequency_map(E)
+        diag, anti = structured_bin_maps(idx_d, idx_s, sg, allow_shared=True)
+        td, ta, n = tag_merged_bins(diag, anti)
+        shared = sorted(set(diag[1:].tolist()) & set(anti.tolist()))
+        assert n == len(shared) and (n == 0) == (structured_bin_maps(idx_d, idx_s, sg) is not None)
+        assert np.array_equal(td & 0xffff, diag) and np.array_equal(ta & 0xffff, anti)
+        tags_d = {int(v & 0xffff): int(v >> 16) for v in td[1:] if v >> 16}
+        tags_a = {int(v & 0xffff): int(v >> 16) for v in ta if v >> 16}
+        assert tags_d == tags_a and sorted(tags_d) == shared and sorted(tags_d.values()) == list(range(1, n + 1))
+        assert td[0] >> 16 == 0
