@@ -120,8 +120,9 @@ struct TileCoord {
                   // -5 % at 4096^2 where the carried plane survives in the cache between sweeps; set per plan)
 };
 
-// Row r of the tile starts at a wave-uniform address; the lane only adds a 32-bit offset, so the accesses use the
-// SGPR-base + VGPR-offset addressing mode (no 64-bit address arithmetic per row).
+// Row r of the tile starts at a wave-uniform address and the lane adds a 32-bit offset.  (hipcc 7.2 still forms a 64-bit
+// per-lane address with one v_lshl_add_u64 per row instead of the SGPR-base addressing mode; the kernels are
+// bandwidth-bound, so this costs issue slots only.)
 __device__ __forceinline__ void load_cols(const double* __restrict__ base, const TileCoord& t, int nx, int lane,
                                           double (&v)[TS]) {
   const double* p = base + (long)t.j0 * nx + t.i0;

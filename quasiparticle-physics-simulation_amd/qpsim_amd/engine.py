@@ -505,8 +505,9 @@ class Engine:
     # -- collisions, generation, reductions -------------------------------------------------------------------
     def make_collision_tables(self, kr0, ks0, rho, idx_diff, idx_sum, sign, cls_packed=None, allow_fast=True,
                               kernel: str = "auto"):
-        """``kernel``: "auto" | "generic" | "wave" | "wave_unstructured" (force a collision kernel; tests, A/B timing)."""
-        """Upload per-gap-class tables ([C,NE,NE], [C,NE]) and maps; returns an opaque handle."""
+        """Upload per-gap-class tables ([C,NE,NE], [C,NE]) and maps; returns an opaque handle.
+
+        ``kernel``: "auto" | "generic" | "wave" | "wave_unstructured" forces a collision kernel (tests, A/B timing)."""
         torch = self.torch
         up = lambda a, dt: None if a is None else torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=self.device)  # noqa: E731
         rho = np.atleast_2d(np.asarray(rho, dtype=np.float64))
