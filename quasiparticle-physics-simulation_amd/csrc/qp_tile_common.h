@@ -122,7 +122,8 @@ struct TileCoord {
 
 // Row r of the tile starts at a wave-uniform address and the lane adds a 32-bit offset.  (hipcc 7.2 still forms a 64-bit
 // per-lane address with one v_lshl_add_u64 per row instead of the SGPR-base addressing mode; the kernels are
-// bandwidth-bound, so this costs issue slots only.)
+// bandwidth-bound, so this costs issue slots only.  Buffer instructions - one resource descriptor per tile, lane offset
+// in one VGPR, row offset as scalar soffset - remove that arithmetic but measured 2-4 % slower on MI355X.)
 __device__ __forceinline__ void load_cols(const double* __restrict__ base, const TileCoord& t, int nx, int lane,
                                           double (&v)[TS]) {
   const double* p = base + (long)t.j0 * nx + t.i0;
