@@ -119,6 +119,16 @@ typedef struct qp_collision_tables {
    * ne <= 64, one wave per pixel with lanes <-> energy bins (deterministic when diag_bin vouches for the bin-map structure,
    * LDS atomics otherwise); otherwise the generic one-thread-per-cell kernel.  The FORCE bits exist for tests. */
   uint32_t flags;
+  /* Optional, for nclass > 1 (non-uniform gap): the reference's kernels are separable in the gap (solver.py:463-490),
+   *   K^r_0 = kr_amp[i][j] (1 + gap^2 pair_inv[i][j]),   K^s_0 = ks_amp[i][j] max(1 - gap^2 pair_inv[i][j], 0),
+   * with kr_amp = (1/tau_r) ((Ei+Ej)/kTc)^2 / kTc, ks_amp = (1/tau_s) (Ei-Ej)^2 / kTc^3 (zero diagonal),
+   * pair_inv = 1 / max(Ei Ej, 1e-30).  When gap_sq[nclass] and pair_inv are given (kr_amp / ks_amp per enabled process),
+   * the register-resident kernel serves gap classes too (ne <= 16): it forms K per pixel from these three shared tables
+   * instead of reading per-class tables.  All NULL: gap classes run the one-wave-per-pixel kernel. */
+  const double* gap_sq;
+  const double* kr_amp;
+  const double* ks_amp;
+  const double* pair_inv;
 } qp_collision_tables;
 #define QP_COLL_FORCE_GENERIC 1u
 #define QP_COLL_FORCE_WAVE 2u

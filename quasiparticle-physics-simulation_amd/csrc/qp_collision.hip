@@ -132,6 +132,10 @@ bool collision_fast_dispatch(int ne, const double* kr0, const double* ks0, const
                              hipStream_t stream);
 
 int collision_fast_supported(int ne);
+bool collision_fast_dispatch_classes(int ne, const double* rho, const int* cls, const double* gap_sq, const double* kr_amp,
+                                     const double* ks_amp, const double* pair_inv, const int* diag_bin, const int* anti_bin,
+                                     double* stash, const uint8_t* flags, long ncell, const double* sin_, double* sout,
+                                     double* ph, double dE, double dt, int en_r, int en_s, int upd, hipStream_t stream);
 
 struct WaveCollView {
   int ne, nw, nclass;
@@ -175,6 +179,15 @@ extern "C" int qp_collision_step(const qp_collision_tables* t, const uint8_t* fl
                                   state_in, state_out, phonon, dE, dt, enable_recombination, enable_scattering,
                                   update_phonons, (hipStream_t)stream))
     return qp::check_launch("qp_collision_step(fast)");
+  // gap classes with the separable kernel tables: register kernel that forms K per pixel
+  if (t->diag_bin && t->nclass > 1 && t->gap_sq && t->pair_inv && t->cls &&
+      (!(enable_recombination && t->kr0) || t->kr_amp) && (!(enable_scattering && t->ks0) || t->ks_amp) &&
+      !(t->flags & (QP_COLL_FORCE_GENERIC | QP_COLL_FORCE_WAVE)) && shared_ok &&
+      qp::collision_fast_dispatch_classes(t->ne, t->rho, t->cls, t->gap_sq, enable_recombination ? t->kr_amp : nullptr,
+                                          enable_scattering ? t->ks_amp : nullptr, t->pair_inv, t->diag_bin, t->anti_bin,
+                                          ph_scratch, flags, (long)ncell, state_in, state_out, phonon, dE, dt,
+                                          enable_recombination, enable_scattering, update_phonons, (hipStream_t)stream))
+    return qp::check_launch("qp_collision_step(fast, gap classes)");
   // NE <= 64: one wave per pixel (any class map; LDS atomics unless the host vouched for the bin-map structure)
   if (!(t->flags & QP_COLL_FORCE_GENERIC)) {
     qp::WaveCollView wv{t->ne, t->nw, t->nclass, t->kr0, t->ks0, t->rho, t->idx_diff, t->idx_sum, t->sign, t->cls,

@@ -10,6 +10,10 @@ QP_DEFINE_DIAG(2) QP_DEFINE_DIAG(3) QP_DEFINE_DIAG(4) QP_DEFINE_DIAG(5) QP_DEFIN
 
 QP_DIAG_NE_LIST(QP_DECLARE_DIAG)
 
+// gap-class (PARAM) variants: the single-pass sizes of this unit
+#define QP_DIAGP_NE_LIST(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+QP_DIAGP_NE_LIST(QP_DEFINE_DIAGP)
+
 __global__ void __launch_bounds__(256) collision_none_kernel(const uint8_t* __restrict__ flags, long ncell, long total,
                                                              const double* __restrict__ sin_, double* __restrict__ sout) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -24,7 +28,7 @@ bool collision_fast_dispatch(int ne, const double* kr0, const double* ks0, const
                              double* sout, double* ph, double dE, double dt, int en_r, int en_s, int upd,
                              hipStream_t stream) {
   if (ncell >= (1L << 28)) return false;
-  CollFastView v{kr0, ks0, rho, diag_bin, anti_bin, stash};
+  CollFastView v{kr0, ks0, rho, diag_bin, anti_bin, stash, nullptr, nullptr, nullptr, nullptr, nullptr};
   const bool s = en_s && ks0, r = en_r && kr0, u = upd && (s || r);
   diag_launcher_t fn = nullptr;
   switch (ne) {
@@ -38,6 +42,27 @@ bool collision_fast_dispatch(int ne, const double* kr0, const double* ks0, const
     hipLaunchKernelGGL(collision_none_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, flags, ncell,
                        total, sin_, sout);
     return true;
+  }
+  fn(v, flags, ncell, sin_, sout, ph, dE, dt, u, stream);
+  return true;
+}
+
+// Gap classes: `rho` is [nclass][ne]; kr_amp / ks_amp stand in for kr0 / ks0 (NULL = process off).  False when this NE has
+// no PARAM instantiation.
+bool collision_fast_dispatch_classes(int ne, const double* rho, const int* cls, const double* gap_sq, const double* kr_amp,
+                                     const double* ks_amp, const double* pair_inv, const int* diag_bin, const int* anti_bin,
+                                     double* stash, const uint8_t* flags, long ncell, const double* sin_, double* sout,
+                                     double* ph, double dE, double dt, int en_r, int en_s, int upd, hipStream_t stream) {
+  if (ncell >= (1L << 28)) return false;
+  CollFastView v{nullptr, nullptr, rho, diag_bin, anti_bin, stash, cls, gap_sq, kr_amp, ks_amp, pair_inv};
+  const bool s = en_s && ks_amp, r = en_r && kr_amp, u = upd && (s || r);
+  if (!s && !r) return false;
+  diag_launcher_t fn = nullptr;
+  switch (ne) {
+#define QP_CASE(N) case N: fn = (s && r) ? diag_launcherp_##N##_11 : r ? diag_launcherp_##N##_01 : diag_launcherp_##N##_10; break;
+    QP_DIAGP_NE_LIST(QP_CASE)
+#undef QP_CASE
+    default: return false;
   }
   fn(v, flags, ncell, sin_, sout, ph, dE, dt, u, stream);
   return true;

@@ -28,7 +28,8 @@ class CollisionTables(C.Structure):
     """Mirror of ``qp_collision_tables``."""
     _fields_ = [("ne", C.c_int32), ("nw", C.c_int32), ("nclass", C.c_int32),
                 ("kr0", c_dp), ("ks0", c_dp), ("rho", c_dp), ("idx_diff", c_dp), ("idx_sum", c_dp),
-                ("sign", c_dp), ("cls", c_dp), ("diag_bin", c_dp), ("anti_bin", c_dp), ("flags", C.c_uint32)]
+                ("sign", c_dp), ("cls", c_dp), ("diag_bin", c_dp), ("anti_bin", c_dp), ("flags", C.c_uint32),
+                ("gap_sq", c_dp), ("kr_amp", c_dp), ("ks_amp", c_dp), ("pair_inv", c_dp)]
 
 
 class RectPlan(C.Structure):

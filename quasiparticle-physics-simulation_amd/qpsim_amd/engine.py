@@ -504,10 +504,12 @@ class Engine:
 
     # -- collisions, generation, reductions -------------------------------------------------------------------
     def make_collision_tables(self, kr0, ks0, rho, idx_diff, idx_sum, sign, cls_packed=None, allow_fast=True,
-                              kernel: str = "auto"):
+                              kernel: str = "auto", gap_params: dict | None = None):
         """Upload per-gap-class tables ([C,NE,NE], [C,NE]) and maps; returns an opaque handle.
 
-        ``kernel``: "auto" | "generic" | "wave" | "wave_unstructured" forces a collision kernel (tests, A/B timing)."""
+        ``kernel``: "auto" | "generic" | "wave" | "wave_unstructured" forces a collision kernel (tests, A/B timing).
+        ``gap_params`` (gap classes only): ``dict(E=E_bins, gaps=class_gaps, tau_r=, tau_s=, T_c=)`` - lets the register
+        kernel form K^r_0, K^s_0 per pixel from gap-independent tables (they are separable in the gap)."""
         torch = self.torch
         up = lambda a, dt: None if a is None else torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=self.device)  # noqa: E731
         rho = np.atleast_2d(np.asarray(rho, dtype=np.float64))
@@ -541,13 +543,30 @@ class Engine:
         if kernel == "wave_unstructured":
             kernel = "wave"
         wave_ok = ne <= 64 and nw <= 192
+        h["gap_sq"] = h["kr_amp"] = h["ks_amp"] = h["pair_inv"] = None
+        classes_ok = False
+        if nclass > 1 and gap_params is not None and structure is not None and ne <= 16:
+            from .tables import KB_UEV_PER_K
+            E = np.asarray(gap_params["E"], dtype=np.float64)
+            kTc = KB_UEV_PER_K * float(gap_params["T_c"])
+            psum, pdiff = E[:, None] + E[None, :], E[:, None] - E[None, :]
+            h["pair_inv"] = up(1.0 / np.maximum(E[:, None] * E[None, :], 1e-30), np.float64)
+            h["gap_sq"] = up(np.asarray(gap_params["gaps"], dtype=np.float64) ** 2, np.float64)
+            if kr0 is not None:
+                h["kr_amp"] = up((1.0 / float(gap_params["tau_r"])) * (psum / kTc) ** 2 / kTc, np.float64)
+            if ks0 is not None:
+                ksa = (1.0 / float(gap_params["tau_s"])) * pdiff ** 2 / kTc ** 3
+                np.fill_diagonal(ksa, 0.0)
+                h["ks_amp"] = up(ksa, np.float64)
+            classes_ok = True
         h["kernel"] = ("generic" if (kernel == "generic" or not wave_ok) else
-                       "register" if (kernel == "auto" and structure is not None and nclass == 1
+                       "register" if (kernel == "auto" and structure is not None and (nclass == 1 or classes_ok)
                                       and bool(self.lib.qp_collision_register_kernel_available(ne))) else "wave")
         h["fast"] = h["kernel"] != "generic"      # no accumulator planes needed
         h["struct"] = _hip.CollisionTables(ne, nw, nclass, _ptr(h["kr0"]), _ptr(h["ks0"]), _ptr(h["rho"]),
                                            _ptr(h["idx_diff"]), _ptr(h["idx_sum"]), _ptr(h["sign"]), _ptr(h["cls"]),
-                                           _ptr(h["diag_bin"]), _ptr(h["anti_bin"]), flag_bits)
+                                           _ptr(h["diag_bin"]), _ptr(h["anti_bin"]), flag_bits,
+                                           _ptr(h["gap_sq"]), _ptr(h["kr_amp"]), _ptr(h["ks_amp"]), _ptr(h["pair_inv"]))
         return h
 
     def collide(self, tables, state, state_out, phonon, dE, dt, en_r, en_s, update_phonons):

@@ -385,7 +385,8 @@ def run_2d_crank_nicolson(
               if enable_recombination else None)
     ks_tab = (np.stack([scattering_kernel_base(E_bins, float(g), tau_s_eff, T_c) for g in class_gaps])
               if enable_scattering else None)
-    ctab = eng.make_collision_tables(kr_tab, ks_tab, rho_tab, idx_diff, idx_sum, diff_sign, cls)
+    ctab = eng.make_collision_tables(kr_tab, ks_tab, rho_tab, idx_diff, idx_sum, diff_sign, cls,
+                                     gap_params=dict(E=E_bins, gaps=class_gaps, tau_r=tau_r_eff, tau_s=tau_s_eff, T_c=T_c))
 
     # initial quasiparticle state (solver.py:1240-1283)
     if custom_state is not None:

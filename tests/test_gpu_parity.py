@@ -957,3 +957,45 @@ def test_tiled_paths_agree_with_per_line_kernels_on_random_geometries(seed):
     eng.adi_steps(fast, a, k)
     eng.adi_steps(slow, b, k)
     assert rel_err(eng.download_packed(a), eng.download_packed(b)) < 5e-13
+
+
+@pytest.mark.parametrize("ne,fmax", [(6, 3.0), (12, 3.0), (12, 5.0), (16, 10.0)])
+@pytest.mark.parametrize("en_r,en_s,upd", [(True, True, True), (True, False, True), (False, True, True), (True, True, False)])
+def test_register_collision_kernel_with_gap_classes(O, ne, fmax, en_r, en_s, upd):
+    """Non-uniform gap (per-pixel K_r0_all / K_s0_all / rho_all of solver.py:1203-1232): the register kernel forms K per
+    pixel from the gap-independent amplitude tables; checked against the wave and generic kernels (per-class tables) and
+    the oracle."""
+    from qpsim_amd import tables as T
+    from qpsim_amd.engine import CompiledGeometry, Engine, link_flags
+    rng = np.random.default_rng(ne * 17 + int(en_r) + 2 * int(en_s))
+    mask = rng.random((9, 31)) > 0.2
+    z = np.zeros(mask.shape)
+    eng = Engine(CompiledGeometry(mask, 1.0, link_flags(mask), z, z, z, z))
+    n = int(mask.sum())
+    gaps = np.array([180.0, 171.0, 165.5, 176.25])
+    E, dE = T.build_energy_grid(180.0, 1.0, fmax, ne)          # energy grid of the run; every class gap lies at or below it
+    om, idx_d, idx_s, sg = T.build_phonon_frequency_map(E)
+    rho = np.stack([T.dynes_density_of_states(E, g, 0.1) for g in gaps])
+    kr = np.stack([T.recombination_kernel_base(E, g, 500.0, 1.2) for g in gaps])
+    ks = np.stack([T.scattering_kernel_base(E, g, 400.0, 1.2) for g in gaps])
+    cls = rng.integers(0, gaps.size, size=n)
+    state = rng.random((ne, n)) * rho[cls].T * rng.choice([1e-5, 1e-2, 0.5, 0.9], size=n)[None, :]
+    ph = T.thermal_phonon_occupation(om, 0.3)[:, None] * (0.5 + rng.random((om.size, n)))
+    params = dict(E=E, gaps=gaps, tau_r=500.0, tau_s=400.0, T_c=1.2)
+    outs = {}
+    for kern in ("auto", "wave", "generic"):
+        tab = eng.make_collision_tables(kr, ks, rho, idx_d, idx_s, sg, cls, kernel=kern, gap_params=params)
+        assert tab["kernel"] == ("register" if kern == "auto" else kern)
+        s_in, p_dev = eng.upload_packed(state), eng.upload_packed(ph)
+        s_out = eng.empty(ne, eng.ncell)
+        eng.collide(tab, s_in, s_out, p_dev, dE, 0.37, en_r, en_s, upd)
+        outs[kern] = (eng.download_packed(s_out), eng.download_packed(p_dev))
+    for other in ("wave", "generic"):
+        assert rel_err(outs["auto"][0], outs[other][0]) < 1e-12 and rel_err(outs["auto"][1], outs[other][1]) < 1e-11
+    tables = {"rho": rho, "Kr0": kr if en_r else None, "Ks0": ks if en_s else None, "cls": cls, "idx_diff": idx_d,
+              "idx_sum": idx_s, "sign": sg, "dE": dE}
+    s_ref, p_ref = state.copy(), ph.copy()
+    O.collision_step(s_ref, p_ref, tables, 0.37, en_r=en_r, en_s=en_s, update_phonons=upd)
+    assert rel_err(outs["auto"][0], s_ref) < 2e-11 and rel_err(outs["auto"][1], p_ref) < 2e-11
+    # without the separable tables gap classes stay on the wave kernel
+    assert eng.make_collision_tables(kr, ks, rho, idx_d, idx_s, sg, cls)["kernel"] == "wave"
