@@ -78,9 +78,10 @@ class ADIWorkload:
         prof = Path(__file__).resolve().parents[2] / "profiles"
         if self.N != 4096 or self.nfield != 1:
             return None
-        if self.op.rect is not None and (prof / "r01_adi4096_pmc.json").exists():
-            k = json.loads((prof / "r01_adi4096_pmc.json").read_text())["kernels"]
-            return 0.5 * (k["qp::rect_x_kernel"]["hbm_bytes_per_launch"] + k["qp::rect_y_kernel<1>"]["hbm_bytes_per_launch"])
+        if self.op.rect is not None and (prof / "r01_adi4096_pmc_v3.json").exists():
+            k = json.loads((prof / "r01_adi4096_pmc_v3.json").read_text())["kernels"]
+            pick = lambda frag: sum(v["hbm_bytes_per_launch"] for name, v in k.items() if frag in name)  # noqa: E731
+            return 0.5 * (pick("rect_x_kernel<true, 0>") + pick("rect_y_kernel<1, 0>"))
         if self.ring and self.op.tile is not None and (prof / "r01_ring4096_pmc.json").exists():
             k = json.loads((prof / "r01_ring4096_pmc.json").read_text())["kernels"]
             pick = lambda frag: sum(v["hbm_bytes_per_launch"] for name, v in k.items() if frag in name)  # noqa: E731
