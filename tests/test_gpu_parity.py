@@ -999,3 +999,64 @@ def test_register_collision_kernel_with_gap_classes(O, ne, fmax, en_r, en_s, upd
     assert rel_err(outs["auto"][0], s_ref) < 2e-11 and rel_err(outs["auto"][1], p_ref) < 2e-11
     # without the separable tables gap classes stay on the wave kernel
     assert eng.make_collision_tables(kr, ks, rho, idx_d, idx_s, sg, cls)["kernel"] == "wave"
+
+
+def test_full_size_4096_adi_is_linear_and_conservative():
+    """BASELINE headline size, properties that need no oracle: the step is linear in the field (zero boundary sources) and
+    conserves the integral under reflective walls; both tiled sweeps, carried over 3 steps."""
+    import torch
+    from qpsim_amd.engine import DiffusionOperator, Engine, compile_geometry
+    from qpsim_amd.geometry import extract_edge_segments
+    from qpsim_amd.models import BoundaryCondition
+    N = 4096
+    mask = np.ones((N, N), dtype=bool)
+    edges = extract_edge_segments(mask)
+    bcs = {e.edge_id: BoundaryCondition("reflective") for e in edges}
+    eng = Engine(compile_geometry(mask, edges, bcs, 1.0))
+    op = DiffusionOperator(eng, 3, 0.1, dcoef=[6.0, 6.0, 6.0])
+    assert op.rect is not None
+    g = torch.Generator(device=eng.device).manual_seed(7)
+    u = torch.rand((1, N * N), dtype=torch.float64, device=eng.device, generator=g)
+    v = torch.rand((1, N * N), dtype=torch.float64, device=eng.device, generator=g)
+    a, b = 0.37, -1.9
+    planes = torch.cat([u, v, a * u + b * v])
+    before = planes.sum(dim=1)
+    eng.adi_steps(op, planes, 3)
+    after = planes.sum(dim=1)
+    assert float(((after - before).abs() / before.abs()).max()) < 1e-12
+    lin = (planes[2] - (a * planes[0] + b * planes[1])).abs().max() / planes[2].abs().max()
+    assert float(lin) < 1e-13
+    assert float(planes[0].min()) >= 0.0 and float(planes[0].max()) <= 1.0      # maximum principle, r D = 0.3
+
+
+def test_large_collision_update_is_pixel_local():
+    """2048^2 pixels, NE = 12, full physics: the update of a pixel depends on that pixel only - permuting the pixels
+    permutes the result (register kernel, planes of 4.2 M cells)."""
+    import torch
+    from qpsim_amd import tables as T
+    from qpsim_amd.engine import CompiledGeometry, Engine, link_flags
+    N = 2048
+    mask = np.ones((1, N * N), dtype=bool)
+    z = np.zeros(mask.shape)
+    eng = Engine(CompiledGeometry(mask, 1.0, link_flags(mask), z, z, z, z))
+    ne = 12
+    E, dE = T.build_energy_grid(180.0, 1.0, 3.0, ne)
+    om, idx_d, idx_s, sg = T.build_phonon_frequency_map(E)
+    rho = T.dynes_density_of_states(E, 180.0, 0.0)
+    tab = eng.make_collision_tables(T.recombination_kernel_base(E, 180.0, 440.0, 1.2)[None],
+                                    T.scattering_kernel_base(E, 180.0, 440.0, 1.2)[None], rho[None], idx_d, idx_s, sg)
+    assert tab["kernel"] == "register"
+    g = torch.Generator(device=eng.device).manual_seed(3)
+    dev = eng.device
+    occ = torch.rand((1, N * N), dtype=torch.float64, device=dev, generator=g) * 0.6
+    state = torch.as_tensor(rho, device=dev)[:, None] * occ
+    ph = torch.as_tensor(T.thermal_phonon_occupation(om, 0.2), device=dev)[:, None] * (
+        0.5 + torch.rand((om.size, N * N), dtype=torch.float64, device=dev, generator=g))
+    perm = torch.randperm(N * N, device=dev, generator=g)
+    out1, ph1 = torch.empty_like(state), ph.clone()
+    eng.collide(tab, state, out1, ph1, dE, 0.05, True, True, True)
+    state_p, ph_p = state[:, perm].contiguous(), ph[:, perm].contiguous()
+    out2 = torch.empty_like(state)
+    eng.collide(tab, state_p, out2, ph_p, dE, 0.05, True, True, True)
+    assert torch.equal(out2, out1[:, perm]) and torch.equal(ph_p, ph1[:, perm])
+    assert float(out1.min()) >= 0.0 and float(ph1.min()) >= 0.0
