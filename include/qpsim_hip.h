@@ -123,7 +123,7 @@ typedef struct qp_collision_tables {
    *   K^r_0 = kr_amp[i][j] (1 + gap^2 pair_inv[i][j]),   K^s_0 = ks_amp[i][j] max(1 - gap^2 pair_inv[i][j], 0),
    * with kr_amp = (1/tau_r) ((Ei+Ej)/kTc)^2 / kTc, ks_amp = (1/tau_s) (Ei-Ej)^2 / kTc^3 (zero diagonal),
    * pair_inv = 1 / max(Ei Ej, 1e-30).  When gap_sq[nclass] and pair_inv are given (kr_amp / ks_amp per enabled process),
-   * the register-resident kernel serves gap classes too (ne <= 16): it forms K per pixel from these three shared tables
+   * the register-resident kernel serves gap classes too (qp_collision_register_kernel_classes(ne)): it forms K per pixel from these three shared tables
    * instead of reading per-class tables.  All NULL: gap classes run the one-wave-per-pixel kernel. */
   const double* gap_sq;
   const double* kr_amp;
@@ -148,6 +148,8 @@ int qp_collision_step(const qp_collision_tables* t, const uint8_t* flags, int64_
 /* 1 when qp_collision_step has a register-resident kernel for `ne` energy bins (structured, unshared bin maps and one gap
  * class are the other conditions); other sizes <= 64 run the one-wave-per-pixel kernel, larger ones the generic kernel. */
 int qp_collision_register_kernel_available(int32_t ne);
+/* 1 when the register-resident kernel also has its gap-class variant for `ne` (single-pass sizes: ne <= 16, 18, 20, 24, 30). */
+int qp_collision_register_kernel_classes(int32_t ne);
 
 /*
  * Explicit fixed-bath collision helpers of the reference's step API (not on its time loop; API parity):

@@ -132,6 +132,7 @@ bool collision_fast_dispatch(int ne, const double* kr0, const double* ks0, const
                              hipStream_t stream);
 
 int collision_fast_supported(int ne);
+int collision_fast_classes_supported(int ne);
 bool collision_fast_dispatch_classes(int ne, const double* rho, const int* cls, const double* gap_sq, const double* kr_amp,
                                      const double* ks_amp, const double* pair_inv, const int* diag_bin, const int* anti_bin,
                                      double* stash, const uint8_t* flags, long ncell, const double* sin_, double* sout,
@@ -257,3 +258,6 @@ extern "C" int qp_euler_collision(int32_t ne, int64_t ncell, const double* state
 
 // 1 when the register-resident collision kernel is instantiated for this number of energy bins
 extern "C" int qp_collision_register_kernel_available(int32_t ne) { return qp::collision_fast_supported(ne); }
+
+// 2nd bit: the gap-class variant (separable kernel tables, qp_collision_tables::gap_sq ...) exists as well
+extern "C" int qp_collision_register_kernel_classes(int32_t ne) { return qp::collision_fast_classes_supported(ne); }

@@ -13,6 +13,16 @@ QP_DIAG_NE_LIST(QP_DECLARE_DIAG)
 // gap-class (PARAM) variants: the single-pass sizes of this unit
 #define QP_DIAGP_NE_LIST(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
 QP_DIAGP_NE_LIST(QP_DEFINE_DIAGP)
+// ... and the single-pass sizes of the other units
+#define QP_DIAGP_NE_LIST_EXT(X) X(18) X(20) X(24) X(30)
+#define QP_DECLARE_DIAGP(N)                                                                                               \
+  void diag_launcherp_##N##_11(const CollFastView&, const uint8_t*, long, const double*, double*, double*, double, double, \
+                               bool, hipStream_t);                                                                         \
+  void diag_launcherp_##N##_01(const CollFastView&, const uint8_t*, long, const double*, double*, double*, double, double, \
+                               bool, hipStream_t);                                                                         \
+  void diag_launcherp_##N##_10(const CollFastView&, const uint8_t*, long, const double*, double*, double*, double, double, \
+                               bool, hipStream_t);
+QP_DIAGP_NE_LIST_EXT(QP_DECLARE_DIAGP)
 
 __global__ void __launch_bounds__(256) collision_none_kernel(const uint8_t* __restrict__ flags, long ncell, long total,
                                                              const double* __restrict__ sin_, double* __restrict__ sout) {
@@ -61,11 +71,23 @@ bool collision_fast_dispatch_classes(int ne, const double* rho, const int* cls, 
   switch (ne) {
 #define QP_CASE(N) case N: fn = (s && r) ? diag_launcherp_##N##_11 : r ? diag_launcherp_##N##_01 : diag_launcherp_##N##_10; break;
     QP_DIAGP_NE_LIST(QP_CASE)
+    QP_DIAGP_NE_LIST_EXT(QP_CASE)
 #undef QP_CASE
     default: return false;
   }
   fn(v, flags, ncell, sin_, sout, ph, dE, dt, u, stream);
   return true;
+}
+
+// 1 when the gap-class (PARAM) variant exists for this NE
+int collision_fast_classes_supported(int ne) {
+  switch (ne) {
+#define QP_CASE(N) case N: return 1;
+    QP_DIAGP_NE_LIST(QP_CASE)
+    QP_DIAGP_NE_LIST_EXT(QP_CASE)
+#undef QP_CASE
+    default: return 0;
+  }
 }
 
 // list of NE with a register kernel (for the host-side choice / tests)

@@ -4,4 +4,6 @@
 namespace qp {
 QP_DEFINE_DIAG(18)
 QP_DEFINE_DIAG(20)
+QP_DEFINE_DIAGP(18)
+QP_DEFINE_DIAGP(20)
 }  // namespace qp

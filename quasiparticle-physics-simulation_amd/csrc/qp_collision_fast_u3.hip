@@ -3,4 +3,5 @@
 
 namespace qp {
 QP_DEFINE_DIAG(24)
+QP_DEFINE_DIAGP(24)
 }  // namespace qp

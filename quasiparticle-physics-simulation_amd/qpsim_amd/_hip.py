@@ -75,6 +75,7 @@ SIGNATURES = {
     "qp_adi_rect_set_field_halo": (C.c_int, [C.POINTER(RectPlan), C.c_int32, c_dp, c_dp]),
     "qp_nan_pad": (C.c_int, [c_dp, C.c_int64, C.c_int32, c_dp, C.c_double, c_dp, c_dp]),
     "qp_collision_register_kernel_available": (C.c_int, [C.c_int32]),
+    "qp_collision_register_kernel_classes": (C.c_int, [C.c_int32]),
     "qp_adi_tile_plan_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.POINTER(C.c_double), c_dp, c_dp,
                                           c_dp, c_dp, c_dp, C.POINTER(C.POINTER(TilePlan))]),
     "qp_adi_tile_plan_create_var": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_double, c_dp, c_dp, c_dp, c_dp, c_dp,

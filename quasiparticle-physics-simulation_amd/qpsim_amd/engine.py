@@ -545,7 +545,8 @@ class Engine:
         wave_ok = ne <= 64 and nw <= 192
         h["gap_sq"] = h["kr_amp"] = h["ks_amp"] = h["pair_inv"] = None
         classes_ok = False
-        if nclass > 1 and gap_params is not None and structure is not None and ne <= 16:
+        if (nclass > 1 and gap_params is not None and structure is not None
+                and bool(self.lib.qp_collision_register_kernel_classes(ne))):
             from .tables import KB_UEV_PER_K
             E = np.asarray(gap_params["E"], dtype=np.float64)
             kTc = KB_UEV_PER_K * float(gap_params["T_c"])

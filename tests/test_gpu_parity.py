@@ -959,7 +959,7 @@ def test_tiled_paths_agree_with_per_line_kernels_on_random_geometries(seed):
     assert rel_err(eng.download_packed(a), eng.download_packed(b)) < 5e-13
 
 
-@pytest.mark.parametrize("ne,fmax", [(6, 3.0), (12, 3.0), (12, 5.0), (16, 10.0)])
+@pytest.mark.parametrize("ne,fmax", [(6, 3.0), (12, 3.0), (12, 5.0), (16, 10.0), (24, 3.0), (30, 3.0)])
 @pytest.mark.parametrize("en_r,en_s,upd", [(True, True, True), (True, False, True), (False, True, True), (True, True, False)])
 def test_register_collision_kernel_with_gap_classes(O, ne, fmax, en_r, en_s, upd):
     """Non-uniform gap (per-pixel K_r0_all / K_s0_all / rho_all of solver.py:1203-1232): the register kernel forms K per
@@ -991,12 +991,14 @@ def test_register_collision_kernel_with_gap_classes(O, ne, fmax, en_r, en_s, upd
         eng.collide(tab, s_in, s_out, p_dev, dE, 0.37, en_r, en_s, upd)
         outs[kern] = (eng.download_packed(s_out), eng.download_packed(p_dev))
     for other in ("wave", "generic"):
-        assert rel_err(outs["auto"][0], outs[other][0]) < 1e-12 and rel_err(outs["auto"][1], outs[other][1]) < 1e-11
+        assert rel_err(outs["auto"][0], outs[other][0]) < 1e-12
+        assert rel_err(outs["auto"][1], outs[other][1]) < (1e-11 if ne <= 16 else PHONON_TOL)
     tables = {"rho": rho, "Kr0": kr if en_r else None, "Ks0": ks if en_s else None, "cls": cls, "idx_diff": idx_d,
               "idx_sum": idx_s, "sign": sg, "dE": dE}
     s_ref, p_ref = state.copy(), ph.copy()
     O.collision_step(s_ref, p_ref, tables, 0.37, en_r=en_r, en_s=en_s, update_phonons=upd)
-    assert rel_err(outs["auto"][0], s_ref) < 2e-11 and rel_err(outs["auto"][1], p_ref) < 2e-11
+    assert rel_err(outs["auto"][0], s_ref) < (2e-11 if ne <= 16 else 1e-10)
+    assert rel_err(outs["auto"][1], p_ref) < (2e-11 if ne <= 16 else PHONON_TOL)
     # without the separable tables gap classes stay on the wave kernel
     assert eng.make_collision_tables(kr, ks, rho, idx_d, idx_s, sg, cls)["kernel"] == "wave"
 
