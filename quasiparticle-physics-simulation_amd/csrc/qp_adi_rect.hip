@@ -171,8 +171,7 @@ __global__ void __launch_bounds__(64) rect_x_kernel(RectView v, double* __restri
 //            MODE 3 (reduce): src = rhs of an x-solve; only its reduced right-hand sides are formed (nothing stored)
 // ---------------------------------------------------------------------------------------------------------
 template <int MODE, int STREAM>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == 0 ? 3 : (MODE == 2 ? 3 : 2), 8)))
-rect_y_kernel(RectView v, const double* src, double* dst) {  // src may alias dst
+__global__ void __launch_bounds__(64) rect_y_kernel(RectView v, const double* src, double* dst) {  // src may alias dst
   __shared__ double lds[LDS_DOUBLES];
   const int lane = threadIdx.x;
   const TileCoord t = tile_coord<STREAM>(v.d);
