@@ -59,6 +59,7 @@ const char* qp_last_error(void);
 
 /* Geometry + per-field diffusivity description passed to the general diffusion kernels. */
 typedef struct qp_grid_desc {
+  uint32_t struct_size;    /* sizeof(qp_grid_desc) as the CALLER compiled it; a mismatch is QP_ERR_INVALID_ARGUMENT */
   int32_t ny, nx;          /* grid extent; ncell = ny*nx */
   int32_t nfield;          /* planes in the batch */
   const uint8_t* flags;    /* [ncell] */
@@ -95,6 +96,9 @@ int qp_implicit_sweep(const qp_grid_desc* g, double r, int dir, const double* rh
  * gap class (solver.py:1203-1232 copies per-pixel tables; here only one table set per distinct gap is kept).
  */
 typedef struct qp_collision_tables {
+  uint32_t struct_size;    /* sizeof(qp_collision_tables) as the CALLER compiled it: a binding written against another
+                            * revision of this header (fewer / more members) is rejected with QP_ERR_INVALID_ARGUMENT
+                            * instead of being read past its end */
   int32_t ne;              /* quasiparticle energy bins */
   int32_t nw;              /* phonon bins */
   int32_t nclass;          /* distinct gap classes (1 = uniform) */
@@ -138,7 +142,10 @@ typedef struct qp_collision_tables {
  * One local coupled quasiparticle-phonon collision update of every interior cell
  * (solver.py:703-791 per pixel, :794-875 the pixel loops).  state_in [ne][ncell] and phonon [nw][ncell]
  * are read as the OLD values; the new quasiparticle density goes to state_out (must not alias state_in),
- * phonons are updated in place when update_phonons != 0.  ph_scratch holds 2*nw*ncell doubles.
+ * phonons are updated in place when update_phonons != 0.
+ * ph_scratch: the generic one-thread-per-cell kernel (ne > 64 or QP_COLL_FORCE_GENERIC) needs 2*nw*ncell doubles of
+ * accumulators when phonons are updated; the register-resident kernels need 2*(merged bins)*ncell doubles only when
+ * QP_COLL_SHARED_BINS is set and both processes update phonons (see diag_bin above); every other case takes NULL.
  * Cells whose flags lack QP_FLAG_ACTIVE are copied through unchanged.
  */
 int qp_collision_step(const qp_collision_tables* t, const uint8_t* flags, int64_t ncell, const double* state_in,
@@ -174,7 +181,8 @@ int qp_add_scaled(int64_t n, double* state, const double* g, double scale, void*
 
 /*
  * Pauli-guard statistics over state[ne][ncell] (solver.py:967-996): occupation f = n / rho where rho > 1e-30.
- * out_vals[0] = max f, out_idx[0] = its linear index ie*ncell + p (first in C order on ties),
+ * out_vals[0] = max f, out_idx[0] = its linear index ie*ncell + p (first in C order on ties; a NaN occupation counts as
+ * the maximum and the first NaN wins, as np.argmax does),
  * out_idx[1] = first linear index with rho <= 1e-30 and n > density_floor, or -1.
  * workspace: qp_pauli_workspace_bytes() bytes.  Results land in device memory (copy them back yourself).
  */
@@ -194,6 +202,8 @@ int qp_absmax(const double* a, int64_t n, void* workspace, double* out_val, void
 
 /* y[i] += alpha * x[i] */
 int qp_axpy(int64_t n, double alpha, const double* x, double* y, void* stream);
+/* y[i] = alpha * x[i] + beta * y[i]   (direction update of the Chebyshev-accelerated exact-CN iteration) */
+int qp_axpby(int64_t n, double alpha, const double* x, double beta, double* y, void* stream);
 
 /*
  * Fast CN-ADI path: full ny x nx rectangle, one diffusivity per field, one boundary condition per side.

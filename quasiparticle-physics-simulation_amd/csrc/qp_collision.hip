@@ -65,9 +65,11 @@ __global__ void __launch_bounds__(256) collision_generic_kernel(CollView t, cons
       const double rho_j = rho[j];
       const double qj = rho_j * fmax(1.0 - nj / fmax(rho_j, 1e-30), 0.0);
       if (use_s && j != i) {
-        const double pd = ph[(long)t.idx_diff[i * NE + j] * ncell + p];  // |Ei-Ej| bin, symmetric in (i,j)
-        const double np_ij = t.sign[i * NE + j] > 0 ? 1.0 + pd : pd;
-        const double np_ji = t.sign[j * NE + i] > 0 ? 1.0 + pd : pd;
+        // the reference's own maps are symmetric in (i, j); caller-supplied tables of the step API need not be
+        const double pd_ij = ph[(long)t.idx_diff[i * NE + j] * ncell + p];
+        const double pd_ji = ph[(long)t.idx_diff[j * NE + i] * ncell + p];
+        const double np_ij = t.sign[i * NE + j] > 0 ? 1.0 + pd_ij : pd_ij;
+        const double np_ji = t.sign[j * NE + i] > 0 ? 1.0 + pd_ji : pd_ji;
         g_s += ks[j * NE + i] * np_ji * nj;
         l_s += ks[i * NE + j] * np_ij * qj;
       }
@@ -161,6 +163,11 @@ extern "C" int qp_collision_step(const qp_collision_tables* t, const uint8_t* fl
                                  double dE, double dt, int enable_recombination, int enable_scattering,
                                  int update_phonons, void* stream) {
   QP_REQUIRE(t != nullptr, "tables are NULL");
+  if (t->struct_size != sizeof(qp_collision_tables)) {
+    qp::set_error("qp_collision_step: qp_collision_tables.struct_size is %u, this library expects %zu (binding built against "
+                  "another header revision)", t->struct_size, sizeof(qp_collision_tables));
+    return QP_ERR_INVALID_ARGUMENT;
+  }
   QP_REQUIRE(t->ne > 0 && t->nw > 0 && t->nclass > 0, "ne, nw, nclass must be positive");
   QP_REQUIRE(t->rho && t->idx_diff && t->idx_sum && t->sign, "rho / idx maps / sign must be non-NULL");
   QP_REQUIRE(t->nclass == 1 || t->cls, "cls is required when nclass > 1");

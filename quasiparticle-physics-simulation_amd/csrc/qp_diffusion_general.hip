@@ -18,6 +18,11 @@ void set_error(const char* fmt, ...) {
 
 int validate_grid(const qp_grid_desc* g, const char* who) {
   if (!g) { set_error("%s: grid descriptor is NULL", who); return QP_ERR_INVALID_ARGUMENT; }
+  if (g->struct_size != sizeof(qp_grid_desc)) {
+    set_error("%s: qp_grid_desc.struct_size is %u, this library expects %zu (binding built against another header revision)",
+              who, g->struct_size, sizeof(qp_grid_desc));
+    return QP_ERR_INVALID_ARGUMENT;
+  }
   if (g->ny <= 0 || g->nx <= 0 || g->nfield <= 0) {
     set_error("%s: ny, nx, nfield must be positive (got %d, %d, %d)", who, g->ny, g->nx, g->nfield);
     return QP_ERR_INVALID_ARGUMENT;
@@ -117,7 +122,7 @@ __global__ void __launch_bounds__(128) thomas_lines_kernel(GridView g, double r,
 
 extern "C" {
 
-int qp_version(void) { return 100; }
+int qp_version(void) { return 200; }
 
 const char* qp_last_error(void) { return qp::g_err; }
 

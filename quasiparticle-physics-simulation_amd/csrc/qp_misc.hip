@@ -58,8 +58,16 @@ struct PauliPartial {
   long forb;
 };
 
+// np.argmax order (solver.py:993): a NaN occupation is the maximum and the first NaN in C order wins; otherwise the
+// largest value, the smallest linear index on ties
+__device__ __forceinline__ bool pauli_better(double of, long ofi, double f, long fi) {
+  const bool on = of != of, fn = f != f;
+  if (on || fn) return on && (!fn || ofi < fi);
+  return of > f || (of == f && ofi < fi);
+}
+
 __device__ __forceinline__ void pauli_merge(double& f, long& fi, long& forb, double of, long ofi, long oforb) {
-  if (of > f || (of == f && ofi < fi)) { f = of; fi = ofi; }
+  if (pauli_better(of, ofi, f, fi)) { f = of; fi = ofi; }
   if (oforb >= 0 && (forb < 0 || oforb < forb)) forb = oforb;
 }
 
@@ -84,7 +92,7 @@ __global__ void __launch_bounds__(256) pauli_partial_kernel(const double* __rest
                                                             double floor_, PauliPartial* part) {
   // f defaults to 0 where rho <= 1e-30 (np.divide(..., where=rho_mask) into zeros, solver.py:987-992);
   // np.argmax returns the first maximum in C order, so ties resolve to the smallest linear index.
-  double f = -1.0;
+  double f = -__builtin_huge_val();
   long fi = 0x7fffffffffffffffL, forb = -1;
   // blockIdx.y strides over energy bins, blockIdx.x over cells: no 64-bit div / mod per element.  Four independent
   // cells per trip so that four loads are in flight per thread (the loop is latency-bound otherwise: ~1.9 TB/s).
@@ -112,7 +120,7 @@ __global__ void __launch_bounds__(256) pauli_partial_kernel(const double* __rest
         double occ = 0.0;
         if (r > 1e-30) occ = n / fmax(r, 1e-30);
         else if (n > floor_ && (forb < 0 || t < forb)) forb = t;
-        if (occ > f || (occ == f && t < fi)) { f = occ; fi = t; }
+        if (pauli_better(occ, t, f, fi)) { f = occ; fi = t; }
       }
     }
   }
@@ -121,7 +129,7 @@ __global__ void __launch_bounds__(256) pauli_partial_kernel(const double* __rest
 
 __global__ void __launch_bounds__(256) pauli_final_kernel(const PauliPartial* part, int nparts, double* out_vals,
                                                           long* out_idx) {
-  double f = -1.0;
+  double f = -__builtin_huge_val();
   long fi = 0x7fffffffffffffffL, forb = -1;
   for (int k = threadIdx.x; k < nparts; k += blockDim.x) pauli_merge(f, fi, forb, part[k].maxf, part[k].maxidx, part[k].forb);
   __shared__ PauliPartial res;
@@ -164,6 +172,12 @@ __global__ void __launch_bounds__(256) axpy_kernel(long n, double alpha, const d
                                                    double* __restrict__ y) {
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x)
     y[t] += alpha * x[t];
+}
+
+__global__ void __launch_bounds__(256) axpby_kernel(long n, double alpha, const double* __restrict__ x, double beta,
+                                                    double* __restrict__ y) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x)
+    y[t] = fma(alpha, x[t], beta * y[t]);
 }
 
 static inline unsigned grid_for(long n) {
@@ -247,6 +261,12 @@ int qp_axpy(int64_t n, double alpha, const double* x, double* y, void* stream) {
   QP_REQUIRE(x && y && n > 0, "bad arguments");
   hipLaunchKernelGGL(qp::axpy_kernel, dim3(qp::grid_for(n)), dim3(256), 0, (hipStream_t)stream, (long)n, alpha, x, y);
   return qp::check_launch("qp_axpy");
+}
+
+int qp_axpby(int64_t n, double alpha, const double* x, double beta, double* y, void* stream) {
+  QP_REQUIRE(x && y && n > 0, "bad arguments");
+  hipLaunchKernelGGL(qp::axpby_kernel, dim3(qp::grid_for(n)), dim3(256), 0, (hipStream_t)stream, (long)n, alpha, x, beta, y);
+  return qp::check_launch("qp_axpby");
 }
 
 }  // extern "C"

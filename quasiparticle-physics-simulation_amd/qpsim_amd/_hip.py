@@ -17,16 +17,25 @@ _lib = None
 c_dp = C.c_void_p  # device pointers travel as raw addresses
 
 
-class GridDesc(C.Structure):
+class _SizedStructure(C.Structure):
+    """Structures whose first member is ``struct_size`` (the library rejects a mismatch with its own sizeof)."""
+
+    @classmethod
+    def make(cls, *values):
+        """Instance with ``struct_size = sizeof`` and the remaining members from ``values`` in declaration order."""
+        return cls(C.sizeof(cls), *values)
+
+
+class GridDesc(_SizedStructure):
     """Mirror of ``qp_grid_desc``."""
-    _fields_ = [("ny", C.c_int32), ("nx", C.c_int32), ("nfield", C.c_int32),
+    _fields_ = [("struct_size", C.c_uint32), ("ny", C.c_int32), ("nx", C.c_int32), ("nfield", C.c_int32),
                 ("flags", c_dp), ("ex", c_dp), ("ey", c_dp), ("sx", c_dp), ("sy", c_dp),
                 ("dcoef", c_dp), ("dfield", c_dp)]
 
 
-class CollisionTables(C.Structure):
+class CollisionTables(_SizedStructure):
     """Mirror of ``qp_collision_tables``."""
-    _fields_ = [("ne", C.c_int32), ("nw", C.c_int32), ("nclass", C.c_int32),
+    _fields_ = [("struct_size", C.c_uint32), ("ne", C.c_int32), ("nw", C.c_int32), ("nclass", C.c_int32),
                 ("kr0", c_dp), ("ks0", c_dp), ("rho", c_dp), ("idx_diff", c_dp), ("idx_sum", c_dp),
                 ("sign", c_dp), ("cls", c_dp), ("diag_bin", c_dp), ("anti_bin", c_dp), ("flags", C.c_uint32),
                 ("gap_sq", c_dp), ("kr_amp", c_dp), ("ks_amp", c_dp), ("pair_inv", c_dp)]
@@ -60,6 +69,7 @@ SIGNATURES = {
     "qp_weighted_sum": (C.c_int, [c_dp, c_dp, C.c_int32, C.c_int64, c_dp, c_dp]),
     "qp_absmax": (C.c_int, [c_dp, C.c_int64, c_dp, c_dp, c_dp]),
     "qp_axpy": (C.c_int, [C.c_int64, C.c_double, c_dp, c_dp, c_dp]),
+    "qp_axpby": (C.c_int, [C.c_int64, C.c_double, c_dp, C.c_double, c_dp, c_dp]),
     "qp_adi_rect_plan_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.POINTER(C.c_double),
                                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32,
                                           C.POINTER(C.POINTER(RectPlan))]),

@@ -299,7 +299,7 @@ class DiffusionOperator:
         if (self.dcoef is None) == (self.dfield is None):
             raise ValueError("give exactly one of dcoef / dfield")
         g = engine
-        self.desc = _hip.GridDesc(g.ny, g.nx, self.nfield, _ptr(g.d_flags), _ptr(g.d_ex), _ptr(g.d_ey), _ptr(g.d_sx),
+        self.desc = _hip.GridDesc.make(g.ny, g.nx, self.nfield, _ptr(g.d_flags), _ptr(g.d_ex), _ptr(g.d_ey), _ptr(g.d_sx),
                                   _ptr(g.d_sy), _ptr(self.dcoef), _ptr(self.dfield))
         # full rectangle + one D per field + one BC per side -> tiled partition-method kernels
         self.rect = None
@@ -323,6 +323,23 @@ class DiffusionOperator:
                     if exc.status != -3:      # QP_ERR_UNSUPPORTED
                         raise
                     self.tile_refused = str(exc)
+
+
+class FrameTicket:
+    """Handle of one asynchronous frame download (``Engine.download_frames_async``)."""
+
+    def __init__(self, slot, done_event, numel: int, shape):
+        self._slot, self._done, self._numel, self._shape = slot, done_event, numel, shape
+        self._frames = None
+
+    def result(self) -> np.ndarray:
+        if self._frames is None:
+            self._done.synchronize()
+            self._frames = self._slot["host"][:self._numel].numpy().reshape(self._shape).copy()
+            if self._slot["ticket"] is self:
+                self._slot["ticket"] = None
+            self._slot = None
+        return self._frames
 
 
 class Engine:
@@ -394,18 +411,50 @@ class Engine:
         """[nfield, ncell] device planes -> host [nfield, ny, nx] frames, NaN outside the mask (reconstruct_field), times
         `scale`; the padding happens on the device, the host only receives.  With ``full_shape`` the engine grid is the
         window at ``offset`` of a larger all-NaN frame (the solver crops padded geometries onto their bounding box)."""
+        return self.download_frames_async(planes, scale, full_shape, offset).result()
+
+    def download_frames_async(self, planes, scale: float = 1.0, full_shape=None, offset=(0, 0)) -> "FrameTicket":
+        """Same frames, but the call only ENQUEUES: the NaN padding runs on the compute stream into a staging buffer, the
+        device-to-host copy runs on a side stream into pinned memory, and the compute stream goes on with the next time
+        step.  ``ticket.result()`` waits for that copy and returns the frames as a fresh NumPy array.  A small ring of
+        staging / pinned buffer pairs is reused; taking a slot whose previous ticket is still open completes that ticket
+        first (its copy has had a whole store interval to finish)."""
         torch = self.torch
         planes = planes.reshape(-1, self.ncell)
         n = planes.shape[0]
-        out = self.empty(n, self.ncell)
-        _hip.check(self.lib.qp_nan_pad(_ptr(self.d_flags), self.ncell, n, _ptr(planes), float(scale), _ptr(out),
+        shape = (n, self.ny, self.nx) if full_shape is None else (n,) + tuple(full_shape)
+        numel = int(np.prod(shape))
+        if not hasattr(self, "_dl_slots"):
+            self._dl_stream = torch.cuda.Stream(device=self.device)
+            self._dl_slots = [{"dev": None, "host": None, "ticket": None} for _ in range(3)]
+            self._dl_next = 0
+        slot = self._dl_slots[self._dl_next]
+        self._dl_next = (self._dl_next + 1) % len(self._dl_slots)
+        if slot["ticket"] is not None:
+            slot["ticket"].result()                    # frees the slot (keeps the frames inside the ticket)
+        if slot["dev"] is None or slot["dev"].numel() < numel:
+            slot["dev"] = self.empty(numel)
+            slot["host"] = torch.empty(numel, dtype=torch.float64).pin_memory()
+        stage = slot["dev"][:numel]
+        compute = torch.cuda.current_stream(self.device)
+        embed = full_shape is not None and tuple(full_shape) != (self.ny, self.nx)
+        pad_out = self.scratch("nan_pad", n * self.ncell)[:n * self.ncell] if embed else stage
+        _hip.check(self.lib.qp_nan_pad(_ptr(self.d_flags), self.ncell, n, _ptr(planes), float(scale), _ptr(pad_out),
                                        self.stream), "qp_nan_pad")
-        out = out.view(n, self.ny, self.nx)
-        if full_shape is not None and tuple(full_shape) != (self.ny, self.nx):
-            full = torch.full((n,) + tuple(full_shape), float("nan"), dtype=torch.float64, device=self.device)
-            full[:, offset[0]:offset[0] + self.ny, offset[1]:offset[1] + self.nx] = out
-            out = full
-        return out.cpu().numpy()
+        if embed:
+            full = stage.view(shape)
+            full.fill_(float("nan"))
+            full[:, offset[0]:offset[0] + self.ny, offset[1]:offset[1] + self.nx] = pad_out.view(n, self.ny, self.nx)
+        ready = torch.cuda.Event()
+        ready.record(compute)
+        self._dl_stream.wait_event(ready)
+        with torch.cuda.stream(self._dl_stream):
+            slot["host"][:numel].copy_(stage, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(self._dl_stream)
+        ticket = FrameTicket(slot, done, numel, shape)
+        slot["ticket"] = ticket
+        return ticket
 
     def masked_sum(self, plane) -> float:
         """Sum of one plane over the cells inside the mask (holes hold 0 by invariant)."""
@@ -450,13 +499,40 @@ class Engine:
         self.sweep(op, 1, t2, res)
         return res
 
-    def cn_exact_step(self, op: DiffusionOperator, u, rtol: float = 1e-13, max_iter: int = 400):
-        """Unsplit CN step (I - rL)u' = (I + rL)u + 2rS by ADI-preconditioned Richardson iteration, in place.
+    def _precondition(self, op: DiffusionOperator, res) -> None:
+        """res <- (I - rLy)^-1 (I - rLx)^-1 res: the ADI factorisation applied as preconditioner."""
+        if op.rect is not None:
+            _hip.check(self.lib.qp_adi_rect_solve(op.rect.handle, _ptr(res), self.stream), "qp_adi_rect_solve")
+        elif op.tile is not None:
+            _hip.check(self.lib.qp_adi_tile_solve(op.tile.handle, _ptr(res), self.stream), "qp_adi_tile_solve")
+        else:
+            self.sweep(op, 0, res, res)
+            self.sweep(op, 1, res, res)
+
+    def cn_contraction_bound(self, op: DiffusionOperator) -> float:
+        """Upper estimate of the contraction factor of the plain ADI-preconditioned Richardson iteration,
+        (a lx / (1 + a lx)) (a ly / (1 + a ly)) with a = r max D and l = the Gershgorin bound of -L_dir (4 + boundary term)."""
+        cached = getattr(op, "_cn_rho", None)
+        if cached is not None:
+            return cached
+        dmax = float(op.dcoef.max().item()) if op.dcoef is not None else float(op.dfield.max().item())
+        a = op.r * dmax
+        lx = a * (4.0 + float(self.geom.ex.max())) if self.nx > 1 else a * float(self.geom.ex.max())
+        ly = a * (4.0 + float(self.geom.ey.max())) if self.ny > 1 else a * float(self.geom.ey.max())
+        op._cn_rho = (lx / (1.0 + lx)) * (ly / (1.0 + ly))
+        return op._cn_rho
+
+    def cn_exact_step(self, op: DiffusionOperator, u, rtol: float = 1e-13, max_iter: int = 2000):
+        """Unsplit CN step (I - rL)u' = (I + rL)u + 2rS by ADI-preconditioned iteration, in place.
 
         The ADI factorisation M = (I-rLx)(I-rLy) differs from A = I - rL by r^2 Lx Ly, so
         v <- v + M^-1 (R - A v) contracts with factor rho(Tx Ty) < 1 (Tx = (I-rLx)^-1 rLx).  The starting
-        guess is the ADI step itself; on strips it is already exact and no iteration runs.
-        Returns the number of correction iterations.
+        guess is the ADI step itself; on strips it is already exact and no iteration runs.  For stiff steps
+        (r D >~ 1: contraction factor above 0.5) the same residual / preconditioner kernels are driven by the Chebyshev
+        semi-iteration on the interval [1 - rho, 1] that holds the spectrum of M^-1 A: sqrt(1/(1-rho)) times fewer
+        iterations; if the residual ever grows (non-commuting Lx, Ly on an exotic mask) the plain iteration takes over.
+        Raises ``RuntimeError`` when ``rtol`` is not reached within ``max_iter`` iterations - the reference's SuperLU solve
+        is exact for any dt, so a silent partial solve would not be a drop-in.  Returns the number of iterations.
         """
         n = op.nfield * self.ncell
         R = self.scratch("cn_R", n).view(op.nfield, self.ncell)
@@ -467,10 +543,55 @@ class Engine:
         self._absmax_into(R, norms[0:1])
         v.copy_(u)
         self.adi_step(op, v)
+        rho = self.cn_contraction_bound(op)
+        if rho > 0.5 and not getattr(op, "_cn_plain", False):
+            its = self._cn_chebyshev(op, R, res, v, norms, rho, rtol, max_iter)
+            if its >= 0:
+                u.copy_(v)
+                return its
+            op._cn_plain = True       # residual grew: spectrum outside the assumed interval; v holds the best iterate
+            its = -its
+        else:
+            its = 0
         # The iteration count hardly changes from one step to the next (same operator, smooth data), and looking at
         # the residual costs a device-to-host round trip: the count of the previous call runs blind, then every
         # iteration is checked.  (Running an iteration more than strictly needed only lowers the residual further.)
-        blind = getattr(op, "_cn_its", 0)
+        blind = its + getattr(op, "_cn_its", 0)
+        first = its
+        while True:
+            self.stencil(op, v, res, -1.0, 1.0, 1.0, 0.0, rin=R, cr=1.0)
+            if its >= blind or its >= max_iter:
+                self._absmax_into(res, norms[1:2])
+                scale, err = (float(x) for x in norms.cpu())
+                if not np.isfinite(err):
+                    raise FloatingPointError("exact-CN iteration diverged (non-finite residual)")
+                if err <= rtol * scale:
+                    break
+                if its >= max_iter:
+                    raise RuntimeError(
+                        f"exact-CN iteration did not reach rtol={rtol:g} in {max_iter} iterations (residual "
+                        f"{err / max(scale, 1e-300):.3g}, estimated contraction factor {rho:.4f}); the step is too stiff "
+                        "(r D = dt D / (2 dx^2) very large) - reduce dt or use diffusion_scheme='adi'.")
+            self._precondition(op, res)
+            _hip.check(self.lib.qp_axpy(n, 1.0, _ptr(res), _ptr(v), self.stream), "qp_axpy")
+            its += 1
+        # next call: one iteration fewer runs blind when this one was already far below the tolerance at its first look
+        done = its - first
+        op._cn_its = done - 1 if (its == blind and done > 0 and err <= 0.01 * rtol * scale) else done
+        u.copy_(v)
+        return its
+
+    def _cn_chebyshev(self, op: DiffusionOperator, R, res, v, norms, rho: float, rtol: float, max_iter: int) -> int:
+        """Chebyshev semi-iteration on M^-1 A (spectrum in [1 - rho, 1]) from the iterate in ``v``.  Returns the iteration
+        count, or minus the count when the residual grew (the caller continues with the plain iteration)."""
+        n = op.nfield * self.ncell
+        d = self.scratch("cn_d", n)
+        lmin, lmax = 1.0 - rho, 1.0
+        theta, delta = 0.5 * (lmax + lmin), 0.5 * (lmax - lmin)
+        sigma = theta / delta
+        rk = 1.0 / sigma
+        blind = getattr(op, "_cn_cheb_its", 0)
+        best = float("inf")
         its = 0
         while True:
             self.stencil(op, v, res, -1.0, 1.0, 1.0, 0.0, rin=R, cr=1.0)
@@ -479,20 +600,26 @@ class Engine:
                 scale, err = (float(x) for x in norms.cpu())
                 if not np.isfinite(err):
                     raise FloatingPointError("exact-CN iteration diverged (non-finite residual)")
-                if err <= rtol * scale or its >= max_iter:
+                if err <= rtol * scale:
                     break
-            if op.rect is not None:
-                _hip.check(self.lib.qp_adi_rect_solve(op.rect.handle, _ptr(res), self.stream), "qp_adi_rect_solve")
-            elif op.tile is not None:
-                _hip.check(self.lib.qp_adi_tile_solve(op.tile.handle, _ptr(res), self.stream), "qp_adi_tile_solve")
+                if err > 10.0 * best:
+                    return -max(its, 1)
+                best = min(best, err)
+                if its >= max_iter:
+                    raise RuntimeError(
+                        f"exact-CN (Chebyshev) iteration did not reach rtol={rtol:g} in {max_iter} iterations (residual "
+                        f"{err / max(scale, 1e-300):.3g}, contraction bound {rho:.6f}); reduce dt or use "
+                        "diffusion_scheme='adi'.")
+            self._precondition(op, res)
+            if its == 0:
+                _hip.check(self.lib.qp_axpby(n, 1.0 / theta, _ptr(res), 0.0, _ptr(d), self.stream), "qp_axpby")
             else:
-                self.sweep(op, 0, res, res)
-                self.sweep(op, 1, res, res)
-            _hip.check(self.lib.qp_axpy(n, 1.0, _ptr(res), _ptr(v), self.stream), "qp_axpy")
+                rn = 1.0 / (2.0 * sigma - rk)
+                _hip.check(self.lib.qp_axpby(n, 2.0 * rn / delta, _ptr(res), rn * rk, _ptr(d), self.stream), "qp_axpby")
+                rk = rn
+            _hip.check(self.lib.qp_axpy(n, 1.0, _ptr(d), _ptr(v), self.stream), "qp_axpy")
             its += 1
-        # next call: one iteration fewer runs blind when this one was already far below the tolerance at its first look
-        op._cn_its = its - 1 if (its == blind and its > 0 and err <= 0.01 * rtol * scale) else its
-        u.copy_(v)
+        op._cn_cheb_its = its - 1 if (its == blind and its > 0 and err <= 0.01 * rtol * scale) else its
         return its
 
     def _absmax_into(self, a, out) -> None:
@@ -537,7 +664,16 @@ class Engine:
                 # register kernels park the diagonal's sums in scratch slot `slot` until the anti-diagonal finalises the bin
                 diag, anti, h["merged_slots"] = tag_merged_bins(diag, anti)
             h["diag_bin"], h["anti_bin"] = up(diag, np.int32), up(anti, np.int32)
-        if not allow_fast and kernel == "auto":
+        # the register and wave kernels visit each unordered pair once (K^r_0, K^s_0 and the bin maps of the reference are
+        # symmetric, sign antisymmetric: solver.py:463-490, 668-683); caller-supplied tables of the step API that are not
+        # run the generic kernel, which reads (i, j) and (j, i) separately
+        sym = lambda a: a is None or np.array_equal(np.asarray(a), np.swapaxes(np.asarray(a), -1, -2))  # noqa: E731
+        symmetric = (sym(kr0 if kr0 is None else np.asarray(kr0).reshape(nclass, ne, ne))
+                     and sym(ks0 if ks0 is None else np.asarray(ks0).reshape(nclass, ne, ne))
+                     and sym(idx_diff) and sym(idx_sum)
+                     and np.array_equal(np.asarray(sign), -np.asarray(sign).T))
+        h["symmetric"] = bool(symmetric)
+        if (not allow_fast or not symmetric) and kernel == "auto":
             kernel = "generic"
         flag_bits = {"auto": 0, "generic": 1, "wave": 2, "wave_unstructured": 2}[kernel] | (4 if shared else 0)
         if kernel == "wave_unstructured":
@@ -564,7 +700,7 @@ class Engine:
                        "register" if (kernel == "auto" and structure is not None and (nclass == 1 or classes_ok)
                                       and bool(self.lib.qp_collision_register_kernel_available(ne))) else "wave")
         h["fast"] = h["kernel"] != "generic"      # no accumulator planes needed
-        h["struct"] = _hip.CollisionTables(ne, nw, nclass, _ptr(h["kr0"]), _ptr(h["ks0"]), _ptr(h["rho"]),
+        h["struct"] = _hip.CollisionTables.make(ne, nw, nclass, _ptr(h["kr0"]), _ptr(h["ks0"]), _ptr(h["rho"]),
                                            _ptr(h["idx_diff"]), _ptr(h["idx_sum"]), _ptr(h["sign"]), _ptr(h["cls"]),
                                            _ptr(h["diag_bin"]), _ptr(h["anti_bin"]), flag_bits,
                                            _ptr(h["gap_sq"]), _ptr(h["kr_amp"]), _ptr(h["ks_amp"]), _ptr(h["pair_inv"]))
@@ -604,6 +740,7 @@ class Engine:
         hv, hi, ev = self._guard_slots[self._guard_next]
         self._guard_next ^= 1
         nc = self.ncell if ncell is None else int(ncell)
+        self._guard_ne = tables["ne"]
         _hip.check(self.lib.qp_pauli_stats(_ptr(state), _ptr(tables["rho"]), _ptr(tables["cls"]),
                                            _ptr(self.d_flags if flags is None else flags), tables["ne"], tables["nclass"],
                                            nc, float(floor), _ptr(self._ws), _ptr(self._red_vals), _ptr(self._red_idx),
@@ -618,6 +755,7 @@ class Engine:
         ev.synchronize()
         mx = float(hv[0])
         i0, i1 = int(hi[0]), int(hi[1])
+        i0 = min(max(i0, 0), nc * int(self._guard_ne) - 1)
         top = (i0 // nc, i0 % nc)
         forb = None if i1 < 0 else (i1 // nc, i1 % nc)
         return mx, top, forb

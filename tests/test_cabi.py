@@ -33,19 +33,67 @@ def test_header_symbols_are_exported_and_bound(lib):
     assert sorted(_hip.SIGNATURES) == declared
 
 
+def _header_struct_members(name: str) -> list[str]:
+    """Member names of `typedef struct <name> { ... }` in include/qpsim_hip.h, in declaration order."""
+    text = (ROOT / "include" / "qpsim_hip.h").read_text()
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            names += [part.strip().lstrip("*").strip().split()[-1].lstrip("*") for part in decl.split(",")]
+    return names
+
+
+def _doc_fields(cls_name: str) -> list[tuple[str, str]]:
+    """(member, ctypes type) pairs of the `_fields_` list of class `cls_name` in INTEGRATION.md's binding snippet."""
+    text = (ROOT / "INTEGRATION.md").read_text()
+    block = re.search(r"class %s\(C\.Structure\):.*?_fields_ = \[(.*?)\]\n" % cls_name, text, flags=re.S).group(1)
+    return re.findall(r'\("([a-z_0-9]+)",\s*C\.(c_[a-z0-9_]+)\)', block)
+
+
+@pytest.mark.parametrize("cls_name,c_name", [("GridDesc", "qp_grid_desc"), ("CollisionTables", "qp_collision_tables")])
+def test_documented_binding_matches_header_and_product_binding(cls_name, c_name):
+    """INTEGRATION.md's reference-side ctypes structures = the header's structs = the binding the product uses."""
+    import ctypes as C
+    from qpsim_amd import _hip
+    doc = _doc_fields(cls_name)
+    ours = getattr(_hip, cls_name)._fields_
+    assert [n for n, _ in doc] == _header_struct_members(c_name)
+    assert [n for n, _ in doc] == [n for n, _ in ours]
+    for (name, doc_type), (_, our_type) in zip(doc, ours):
+        assert C.sizeof(getattr(C, doc_type)) == C.sizeof(our_type), name
+    assert doc[0] == ("struct_size", "c_uint32")
+
+
+def test_struct_size_mismatch_is_rejected(lib):
+    """A binding built against another header revision (shorter struct) is refused before anything is read past it."""
+    import ctypes as C
+    from qpsim_amd import _hip
+    t = _hip.CollisionTables.make(4, 7, 1, 8, 8, 8, 8, 8, 8, 0)
+    t.struct_size = 64                     # what a 10-member revision of the struct would have said
+    assert lib.qp_collision_step(C.byref(t), 8, 10, 8, 16, 8, 0, 1.0, 0.1, 1, 1, 1, 0) == -1
+    assert b"struct_size" in lib.qp_last_error()
+    g = _hip.GridDesc.make(4, 4, 1, 8, 8, 8, 8, 8, 8, 0)
+    g.struct_size = 0
+    assert lib.qp_stencil_combine(C.byref(g), 0.1, 8, 0, 8, 1.0, 0.0, 0.0, 0.0, 0.0, 0) == -1
+    assert b"struct_size" in lib.qp_last_error()
+
+
 def test_version_and_error_string(lib):
-    assert lib.qp_version() >= 100
+    assert lib.qp_version() >= 200
     assert isinstance(lib.qp_last_error(), bytes)
 
 
 def test_argument_validation_happens_before_any_launch(lib):
     import ctypes as C
     from qpsim_amd import _hip
-    g = _hip.GridDesc(0, 4, 1, 0, 0, 0, 0, 0, 0, 0)
+    g = _hip.GridDesc.make(0, 4, 1, 0, 0, 0, 0, 0, 0, 0)
     assert lib.qp_stencil_combine(C.byref(g), 0.1, 0, 0, 0, 1.0, 0.0, 0.0, 0.0, 0.0, 0) == -1
     assert b"positive" in lib.qp_last_error()
     assert lib.qp_axpy(0, 1.0, 0, 0, 0) == -1
-    t = _hip.CollisionTables(4, 7, 2, 0, 0, 0, 0, 0, 0, 0)
+    t = _hip.CollisionTables.make(4, 7, 2, 0, 0, 0, 0, 0, 0, 0)
     assert lib.qp_collision_step(C.byref(t), 0, 10, 0, 0, 0, 0, 1.0, 0.1, 1, 1, 1, 0) == -1
 
 

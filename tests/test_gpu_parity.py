@@ -18,6 +18,10 @@ ADI_TOL = 1e-11     # HIP ADI vs the oracle's ADI restatement (same algorithm, f
 # phonon occupations go through (e^{b dt} - 1)/b of solver.py:697 (no expm1): for small |b dt| a last-bit difference
 # between the host and device exp() is amplified by eps/|b dt|, so phonon planes get a looser same-algorithm bound
 PHONON_TOL = 1e-9
+# (recombination, scattering, update_phonons): every template instantiation of the register kernels, including the
+# frozen-phonon single-process ones the BASELINE configs[1] workload (`bench.py --workload c2`) runs
+PROCESS_COMBOS = [(True, True, True), (True, False, True), (False, True, True), (True, True, False), (True, False, False),
+                  (False, True, False)]
 
 
 @pytest.fixture(scope="module")
@@ -425,7 +429,7 @@ def test_rect_fast_path_large_reflective_conserves_mass_and_matches_general():
 
 @pytest.mark.parametrize("ne,fmax", [(2, 3.0), (5, 3.0), (8, 4.0), (12, 3.0), (16, 10.0), (20, 3.0), (32, 3.0), (40, 3.0),
                                      (50, 10.0)])
-@pytest.mark.parametrize("en_r,en_s,upd", [(True, True, True), (True, False, True), (False, True, True), (True, True, False)])
+@pytest.mark.parametrize("en_r,en_s,upd", PROCESS_COMBOS)
 def test_fast_collision_kernel_matches_generic_and_oracle(O, ne, fmax, en_r, en_s, upd):
     """Register-resident diagonal kernel (uniform tables; NE = 50, the reference default, runs the split
     quasiparticle / phonon pair with q re-formed on the fly) vs the generic kernel and the oracle."""
@@ -466,7 +470,7 @@ def test_fast_collision_kernel_matches_generic_and_oracle(O, ne, fmax, en_r, en_
 
 
 @pytest.mark.parametrize("ne,fmax", [(12, 5.0), (18, 10.0), (24, 4.0), (40, 5.0), (50, 5.0)])
-@pytest.mark.parametrize("en_r,en_s,upd", [(True, True, True), (True, False, True), (False, True, True), (True, True, False)])
+@pytest.mark.parametrize("en_r,en_s,upd", PROCESS_COMBOS)
 def test_register_collision_kernel_with_merged_phonon_bins(O, ne, fmax, en_r, en_s, upd):
     """2 E_min / dE integer: phonon bins shared between a diagonal and an anti-diagonal.  The register kernels park the
     diagonal's sums in scratch and finalise the bin once; checked against the generic kernel and the oracle."""
@@ -960,7 +964,7 @@ def test_tiled_paths_agree_with_per_line_kernels_on_random_geometries(seed):
 
 
 @pytest.mark.parametrize("ne,fmax", [(6, 3.0), (12, 3.0), (12, 5.0), (16, 10.0), (24, 3.0), (30, 3.0)])
-@pytest.mark.parametrize("en_r,en_s,upd", [(True, True, True), (True, False, True), (False, True, True), (True, True, False)])
+@pytest.mark.parametrize("en_r,en_s,upd", PROCESS_COMBOS)
 def test_register_collision_kernel_with_gap_classes(O, ne, fmax, en_r, en_s, upd):
     """Non-uniform gap (per-pixel K_r0_all / K_s0_all / rho_all of solver.py:1203-1232): the register kernel forms K per
     pixel from the gap-independent amplitude tables; checked against the wave and generic kernels (per-class tables) and
