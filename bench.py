@@ -16,10 +16,16 @@ Workloads (``--workload``):
                      members over 8 GPUs; members never communicate, so --gpus N runs 64 N members).
   ring<N>[x<F>]      annulus mask inscribed in N x N (the reference's donut geometry), F fields: masked tiled path;
                      cell-updates count the cells inside the mask only.
-  dd<N>              one N x N scalar field domain-decomposed over the ranks (BASELINE configs[4] = dd8192 at 8 GPUs),
-                     neighbour exchange of interface rows over RCCL; "scaling": "strong".
+  dd<N>[c]           one N x N scalar field (c: NE = 12 coupled step) domain-decomposed over the ranks (BASELINE configs[4] =
+                     dd8192 at 8 GPUs): overlapped-halo decomposition, halo refresh over RCCL every S steps; "scaling":
+                     "strong".  ddx<N>: the exact interface exchange after every sweep (the scheme for stiff steps).
 
-Multi-GPU: independent problems per rank (ensemble sharding, no data-path collective) -> "scaling": "weak".
+Multi-GPU (the driver's `--gpus N`, default workload): the headline value stays the same workload per GPU as at N = 1
+(independent 4096^2 fields, ensemble sharding, no data-path collective -> "scaling": "weak"), and the SAME JSON line
+carries two sub-records measured in the same run:
+  "strong"    dd8192 over the N ranks (north_star: >= 6x at 8 GPUs): value, ms/step, the 1-rank time of the same 8192^2
+              problem measured on rank 0 in this run, the speed-up against it, and the share of the halo exchanges;
+  "ensemble"  BASELINE configs[3]: 64 N independent 256^2 MKID members, NE = 12 full physics, 64 per GPU.
 """
 from __future__ import annotations
 
@@ -50,6 +56,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=512, help="grid edge of the bounded CPU-baseline sample")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with one rank")
+    ap.add_argument("--no-subrecords", action="store_true", help="N > 1: skip the strong-scaling / ensemble sub-records")
+    ap.add_argument("--strong-size", type=int, default=8192, help="grid edge of the strong-scaling sub-record")
     return ap.parse_args()
 
 
@@ -62,6 +70,17 @@ def full_rectangle_problem(N: int):
     bcs = {e.edge_id: BoundaryCondition("reflective") for e in edges}
     init = 1e-4 * (1.0 + np.random.default_rng(0).random((N, N)))
     return mask, edges, bcs, init
+
+
+def host_info() -> dict:
+    """Host cores of the box and the thread settings the CPU baseline ran under (north_star: core count stated)."""
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count()
+    return {"host_cores": os.cpu_count(), "host_cores_usable": usable,
+            "omp_num_threads": os.environ.get("OMP_NUM_THREADS", "unset"),
+            "threads_note": "cores = threads the timed code used: SuperLU solve and the NumPy sweeps are single-threaded"}
 
 
 def cpu_baseline(args, workload: str) -> dict:
@@ -90,10 +109,24 @@ def cpu_baseline(args, workload: str) -> dict:
             el = time.perf_counter() - t0
             if el > 8.0 or steps >= 200:
                 break
+        # second CPU figure of BASELINE.md section 4: the same Peaceman-Rachford ADI step in NumPy (vectorised Thomas sweeps)
+        adi = O.ADIStepper(ops, 6.0, 0.1)
+        g = init.astype(float).copy()
+        asteps = 0
+        t0 = time.perf_counter()
+        while True:
+            g = adi.step_grid(g)
+            asteps += 1
+            ael = time.perf_counter() - t0
+            if ael > 6.0 or asteps >= 200:
+                break
         return {
             "value": N * N * steps / el, "unit": "cell-updates/s", "cores": 1, "kind": "port",
             "sample": (f"oracle unsplit-CN (SuperLU factor once, solve per step) on {N}x{N} scalar field, {steps} steps "
                        f"in {el:.2f}s after {t_setup:.1f}s assembly+factorisation; single-threaded like the reference"),
+            "numpy_adi": {"value": N * N * asteps / ael, "unit": "cell-updates/s",
+                          "sample": f"oracle NumPy ADI (batched Thomas sweeps) on {N}x{N}, {asteps} steps in {ael:.2f}s"},
+            **host_info(),
         }
     ne = 12
     frozen = workload == "c2"
@@ -106,10 +139,83 @@ def cpu_baseline(args, workload: str) -> dict:
           freeze_phonon_dynamics=frozen, scheme="cn")
     el = time.perf_counter() - t0
     return {
+        **host_info(),
         "value": N * N * ne * steps / el, "unit": "cell-updates/s", "cores": 1, "kind": "port",
         "sample": (f"oracle full step (collision half-steps vectorised over pixels + unsplit CN/SuperLU per bin) on {N}x{N}, "
                    f"NE={ne}, {steps} steps incl. operator setup in {el:.2f}s; NumPy, one process"),
     }
+
+
+def timed_steps(wl, steps: int, dev, use_dist: bool, **run_kw) -> float:
+    """Wall time of exactly `steps` steps of `wl`, barrier + device sync on both sides, MAX over ranks."""
+    import torch
+    import torch.distributed as dist
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    sync()
+    t0 = time.perf_counter()
+    wl.run(steps, **run_kw)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    sync()
+    return elapsed
+
+
+def strong_scaling_record(args, dev, world: int, rank: int) -> dict:
+    """north_star's strong-scaling figure, measured in this run: the SAME N x N problem (default 8192^2, BASELINE configs[4])
+    first on rank 0 alone (the other ranks wait at the barrier), then decomposed over all ranks."""
+    import torch
+    import torch.distributed as dist
+    from qpsim_amd import bench_workloads as W
+    N = args.strong_size
+    t1 = torch.zeros(1, dtype=torch.float64, device=dev)
+    if rank == 0:
+        single = W.ADIWorkload(N, dev)
+        single.run(max(args.warmup, 1))
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        single.run(args.steps)
+        torch.cuda.synchronize(dev)
+        t1[0] = time.perf_counter() - t0
+        del single
+        torch.cuda.empty_cache()
+    dist.all_reduce(t1, op=dist.ReduceOp.MAX)        # everybody learns the 1-rank time (and waits for it)
+    one_rank = float(t1.item())
+    wl = W.OverlapDecomposedWorkload(N, dev)
+    spe = wl.block.steps_per_exchange
+    wl.run(max(args.warmup, spe + 1))                 # the warm-up includes at least one halo refresh (RCCL connections)
+    elapsed = timed_steps(wl, args.steps, dev, True)
+    no_xchg = timed_steps(wl, args.steps, dev, True, exchange=False)      # same kernels, refreshes skipped: timing only
+    return {
+        "workload": wl.description, "path": wl.path, "scaling": "strong", "rccl_ranks": dist.get_world_size(),
+        "value": float(N) * N * args.steps / elapsed, "unit": "cell-updates/s", "ms_per_step": 1e3 * elapsed / args.steps,
+        "one_rank_ms_per_step": 1e3 * one_rank / args.steps, "speedup_vs_one_rank": one_rank / elapsed,
+        "exchange_share_of_time": max(0.0, 1.0 - no_xchg / elapsed), "steps_per_halo_refresh": spe,
+        "halo_cells_overhead": wl.halo_overhead,
+        "hbm_frac_of_step_per_gpu": (32.0 * N * N / world * args.steps / elapsed / 1e9) / HBM_PEAK_GBS,
+    }
+
+
+def ensemble_record(args, dev, world: int) -> dict:
+    """BASELINE configs[3]: ensemble of independent 256^2 MKID pixels, NE = 12 full physics, 64 members per GPU
+    (512 at 8 GPUs), members never communicate."""
+    from qpsim_amd import bench_workloads as W
+    wl = W.build("c4", dev)
+    wl.run(max(1, min(args.warmup, 5)))
+    steps = max(1, min(args.steps, 50))
+    elapsed = timed_steps(wl, steps, dev, True)
+    return {"workload": wl.description, "scaling": "weak", "members_total": 64 * world,
+            "value": wl.cell_updates_per_step * world * steps / elapsed, "unit": "cell-updates/s", "steps": steps,
+            "ms_per_step": 1e3 * elapsed / steps, "pixel_steps_per_s": wl.npix * world * steps / elapsed}
 
 
 def main():
@@ -133,43 +239,34 @@ def main():
     wl = W.build(args.workload, dev)
     if args.warmup > 0:
         wl.run(args.warmup)
-
-    def sync():
-        torch.cuda.synchronize(dev)
-        if use_dist:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-
-    sync()
-    t0 = time.perf_counter()
-    wl.run(args.steps)        # exactly `steps` time steps of the hot path, enqueued back to back
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    sync()
+    elapsed = timed_steps(wl, args.steps, dev, use_dist)     # exactly `steps` steps of the hot path, enqueued back to back
 
     # per-kernel timing of the dominant kernel with HIP events on the launch stream (same inputs, same loop)
     roof = wl.roofline(max(5, min(args.steps, 20)))
+    strong = getattr(wl, "scaling", "weak") == "strong"
     value = wl.cell_updates_per_step * world * args.steps / elapsed
     result = {
         "metric": "cell-updates/sec on N×N CN ADI step; achieved HBM GB/s vs roofline",
         "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-        "scaling": getattr(wl, "scaling", "weak"),
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": wl.description, "grid": wl.grid, "fields_per_gpu": wl.nfield,
                    "parallelism": ("single GPU" if world == 1 else
-                                   f"domain decomposition over {world} GPUs (RCCL point-to-point)" if getattr(wl, "scaling", "") == "strong"
-                                   else f"independent problems x{world} (no collective)"),
+                                   f"domain decomposition over {world} GPUs (RCCL point-to-point halo refresh)" if strong
+                                   else f"independent problems x{world} (ensemble sharding, no collective)"),
                    "path": wl.path},
         "roofline": roof,
         "hbm_frac_of_step": (wl.bytes_per_step * args.steps / elapsed / 1e9) / HBM_PEAK_GBS,
     }
     if hasattr(wl, "coll_bytes_per_call"):
         result["pixel_steps_per_s"] = wl.npix * world * args.steps / elapsed
+    del wl
+    torch.cuda.empty_cache()
+    if world > 1 and not args.no_subrecords and args.workload == "adi4096":
+        # north_star's two multi-GPU figures, measured in the same run and reported next to the weak-scaling headline
+        result["strong"] = strong_scaling_record(args, dev, world, rank)
+        result["ensemble"] = ensemble_record(args, dev, world)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0 would hold the others up)
             result["cpu_baseline"] = cpu_baseline(args, args.workload)

@@ -45,6 +45,8 @@ struct RectView {
   RectDims d;
   const double* alpha;          // [nfield]
   const double* tab;            // [2 dirs][nfield][4 variants][T_NSLOT][TS]
+  int compact;                  // every table of the plan has the compact form (table_is_compact): kernels <..., true>
+  const double* ctab;           // [2 dirs][nfield][4 variants][2 parts][CT_PART] compact tables (valid when `compact`)
   const double* lu[2];          // per dir: [nfield][5][2P]  (l1, l2, uinv, u1, u2)
   // reduced right-hand sides, per dir [nfield][2P+2][nlines]: row 0 = y[last] of the chunk before the local block,
   // rows 1..2P = (y_0[0], y_0[last], y_1[0], ...), row 2P+1 = y[0] of the chunk after the block.  The two halo rows
@@ -59,14 +61,28 @@ struct RectView {
   double other_src[2][2];       // [dir][lo/hi]: a-less source of the faces normal to `dir` (x: sx_lo, sx_hi)
 };
 
+// coefficient source of one kernel phase: the full table of (dir, field, variant) in registers, or a part of its compact form
+template <bool COMPACT, int FIRST, int COUNT>
+__device__ __forceinline__ auto coef_source(const RectView& v, int dir, int b, int variant, int lane) {
+  const long t = ((long)dir * v.d.nfield + b) * 4 + variant;
+  if constexpr (COMPACT) {
+    return CoefCompact{as_const(v.ctab + (t * 2 + (FIRST >= T_EW ? 1 : 0)) * CT_PART)};
+  } else {
+    CoefFull c;
+    load_tab<FIRST, COUNT>(v.tab + t * T_NSLOT * TS, lane, c.r);
+    return c;
+  }
+}
+
 __device__ __forceinline__ int chunk_variant(int p, int P) {
   // 0 interior, 1 first, 2 last, 3 single
   return (p == 0 ? 1 : 0) | (p == P - 1 ? 2 : 0);
 }
 
-__device__ __forceinline__ ctab_t table_ptr(const RectView& v, int dir, int b, int variant) {
-  return as_const(v.tab + ((((long)dir * v.d.nfield + b) * 4 + variant) * T_NSLOT) * TS);
+__device__ __forceinline__ const double* table_ptr(const RectView& v, int dir, int b, int variant) {
+  return v.tab + ((((long)dir * v.d.nfield + b) * 4 + variant) * T_NSLOT) * TS;
 }
+
 
 // STREAM is a template parameter of the kernels: the headline configuration (cached accesses) keeps exactly the code it
 // had before the non-temporal variants existed (a run-time branch cost ~3 % there)
@@ -96,39 +112,60 @@ __device__ __forceinline__ TileCoord tile_coord(const RectDims& d) {
 //      E - s F = y_p[last],   F - t E = y_{p+1}[0],     s = a h_p[last], t = a g_{p+1}[0]
 // which is solved here from the four reduced right-hand sides next to the chunk; otherwise the banded solve of
 // rect_reduced_kernel has produced z.
+//
+// Two halves: `ghost_prefetch` issues the loads (unconditional, always in bounds: rows 0 and 2P+1 of `iface` are the halo
+// slots) at the very start of a kernel, ahead of the tile rows; `ghost_finish` does the arithmetic where the values are
+// needed.  Loading them at the point of use put one or two exposed memory round trips into the middle of every tile.
+struct GhostRaw {
+  double q0, q1, q2, q3;
+};
+
 template <int DIR>
-__device__ __forceinline__ void chunk_ghosts(const RectView& v, int b, int p, long line, bool on, double& gl,
+__device__ __forceinline__ GhostRaw ghost_prefetch(const RectView& v, int b, int p, long line) {
+  const int P = DIR == 0 ? v.d.px : v.d.py;
+  const long nlines = DIR == 0 ? v.d.ny : v.d.nx;
+  if (line > nlines - 1) line = nlines - 1;      // lanes beyond the grid: any valid address, result discarded
+  GhostRaw g;
+  if (QP_ABL & 1) { g.q0 = g.q1 = g.q2 = g.q3 = 0.0; return g; }
+  if (v.decoupled[DIR]) {
+    const double* ir = v.iface[DIR] + (long)b * (2 * P + 2) * nlines + line;
+    g.q0 = ir[(long)(2 * p) * nlines];
+    g.q1 = ir[(long)(2 * p + 1) * nlines];
+    g.q2 = ir[(long)(2 * p + 2) * nlines];
+    g.q3 = ir[(long)(2 * p + 3) * nlines];
+  } else {
+    const double* z = v.z[DIR] + (long)b * 2 * P * nlines + line;
+    g.q0 = z[(long)max(2 * p - 1, 0) * nlines];
+    g.q1 = z[(long)min(2 * p + 2, 2 * P - 1) * nlines];
+    g.q2 = g.q3 = 0.0;
+  }
+  return g;
+}
+
+template <int DIR>
+__device__ __forceinline__ void ghost_finish(const RectView& v, int b, int p, bool on, const GhostRaw& g, double& gl,
                                              double& gr) {
   const int P = DIR == 0 ? v.d.px : v.d.py;
   const int pg = p + (DIR == 0 ? v.d.i0 : v.d.j0) / TS;          // global chunk index
   const int PG = DIR == 0 ? v.d.gpx : v.d.gpy;
-  const long nlines = DIR == 0 ? v.d.ny : v.d.nx;
   gl = 0.0;
   gr = 0.0;
-  if (!on) return;
   if (v.decoupled[DIR]) {
-    const double* ir = v.iface[DIR] + (long)b * (2 * P + 2) * nlines + line;
     const ctab_t ic = as_const(v.icoef[DIR] + (long)b * (P + 1) * 3);
-    if (pg > 0) {
-      const double yl = ir[(long)(2 * p) * nlines], yf = ir[(long)(2 * p + 1) * nlines];
-      gl = fma(ic[p * 3], yf, yl) * ic[p * 3 + 2];
-    }
-    if (pg < PG - 1) {
-      const double yl = ir[(long)(2 * p + 2) * nlines], yf = ir[(long)(2 * p + 3) * nlines];
-      gr = fma(ic[(p + 1) * 3 + 1], yl, yf) * ic[(p + 1) * 3 + 2];
-    }
+    if (pg > 0) gl = fma(ic[p * 3], g.q1, g.q0) * ic[p * 3 + 2];
+    if (pg < PG - 1) gr = fma(ic[(p + 1) * 3 + 1], g.q2, g.q3) * ic[(p + 1) * 3 + 2];
   } else {
-    const double* z = v.z[DIR] + (long)b * 2 * P * nlines + line;
-    if (p > 0) gl = z[(long)(2 * p - 1) * nlines];
-    if (p < P - 1) gr = z[(long)(2 * p + 2) * nlines];
+    if (p > 0) gl = g.q0;
+    if (p < P - 1) gr = g.q1;
   }
+  if (!on) gl = gr = 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // x-kernel: finish the x-solve, apply the explicit x-operator, eliminate along y.   buf: rhs1 -> rhs2 in place
 // ---------------------------------------------------------------------------------------------------------
 // EXPLICIT = false is the plain solve (I - a Lx)^-1 used by the exact-CN preconditioner: no explicit operator, no sources.
-template <bool EXPLICIT, int STREAM>
+template <bool EXPLICIT, int STREAM, bool COMPACT>
 __global__ void __launch_bounds__(64) rect_x_kernel(RectView v, double* __restrict__ buf) {
   __shared__ double lds[LDS_DOUBLES];
   const int lane = threadIdx.x;
@@ -136,27 +173,32 @@ __global__ void __launch_bounds__(64) rect_x_kernel(RectView v, double* __restri
   const long ncell = (long)v.d.ny * v.d.nx;
   double* plane = buf + (long)t.b * ncell;
   const double a = as_const(v.alpha)[t.b];
+  const int row = t.j0 + lane;         // lane = row between the transposes
+  const bool row_on = lane < t.nr;
+  // small loads first: interface values of this tile's rows, the x-table (solve + explicit operator), the elimination
+  // slots of the y-table
+  const GhostRaw graw = ghost_prefetch<0>(v, t.b, t.tx, row);
+  const int varx = chunk_variant(t.tx + v.d.i0 / TS, v.d.gpx), vary = chunk_variant(t.ty + v.d.j0 / TS, v.d.gpy);
+  const auto cx = coef_source<COMPACT, T_W, T_EW - T_W>(v, 0, t.b, varx, lane);
+  const auto cy = coef_source<COMPACT, T_EW, T_NSLOT - T_EW>(v, 1, t.b, vary, lane);
   double e[TS];
   load_cols(plane, t, v.d.nx, lane, e);
   transpose64(e, lds, lane);
-  // lane = row from here
-  const int row = t.j0 + lane;
-  const bool row_on = lane < t.nr;
   double gl, gr;
-  chunk_ghosts<0>(v, t.b, t.tx, row, row_on, gl, gr);
-  const ctab_t tx_tab = table_ptr(v, 0, t.b, chunk_variant(t.tx + v.d.i0 / TS, v.d.gpx));
+  ghost_finish<0>(v, t.b, t.tx, row_on, graw, gl, gr);
   e[0] = fma(a, gl, e[0]);
   e[TS - 1] = fma(a, gr, e[TS - 1]);   // gr != 0 only for full-length chunks
-  thomas64(e, tx_tab);
+  thomas64(e, cx);
   double srow = 0.0;                   // sources of the y-faces (up/down) belong to rows 0 and ny-1
   if (row + v.d.j0 == 0) srow += a * v.other_src[1][0];
   if (row + v.d.j0 == v.d.gny - 1) srow += a * v.other_src[1][1];
-  if (EXPLICIT) explicit64(e, gl, gr, tx_tab, row_on ? srow : 0.0);
+  if (EXPLICIT) explicit64(e, gl, gr, cx, row_on ? srow : 0.0);
   transpose64(e, lds, lane);
   // lane = column again
   store_cols(plane, t, v.d.nx, lane, e);
+  if (QP_ABL & 8) return;
   double yf, yl;
-  dots64(e, table_ptr(v, 1, t.b, chunk_variant(t.ty + v.d.j0 / TS, v.d.gpy)), yf, yl);
+  ends64(e, cy, yf, yl);
   if (lane < t.nc) {
     double* ir = v.iface[1] + (long)t.b * (2 * v.d.py + 2) * v.d.nx;
     ir[(long)(2 * t.ty + 1) * v.d.nx + t.i0 + lane] = yf;
@@ -170,7 +212,7 @@ __global__ void __launch_bounds__(64) rect_x_kernel(RectView v, double* __restri
 //            MODE 2 (exit):  src = rhs2, y-solve, dst = u'
 //            MODE 3 (reduce): src = rhs of an x-solve; only its reduced right-hand sides are formed (nothing stored)
 // ---------------------------------------------------------------------------------------------------------
-template <int MODE, int STREAM>
+template <int MODE, int STREAM, bool COMPACT>
 __global__ void __launch_bounds__(64) rect_y_kernel(RectView v, const double* src, double* dst) {  // src may alias dst
   __shared__ double lds[LDS_DOUBLES];
   const int lane = threadIdx.x;
@@ -181,24 +223,26 @@ __global__ void __launch_bounds__(64) rect_y_kernel(RectView v, const double* sr
   const double a = as_const(v.alpha)[t.b];
   const int col = t.i0 + lane;
   const bool col_on = lane < t.nc;
-  const ctab_t ty_tab = table_ptr(v, 1, t.b, chunk_variant(t.ty + v.d.j0 / TS, v.d.gpy));
+  // small loads first (see rect_x_kernel)
+  GhostRaw graw;
+  if (MODE == 1 || MODE == 2) graw = ghost_prefetch<1>(v, t.b, t.ty, col);
+  const int varx = chunk_variant(t.tx + v.d.i0 / TS, v.d.gpx), vary = chunk_variant(t.ty + v.d.j0 / TS, v.d.gpy);
+  const auto cy = coef_source<COMPACT, T_W, MODE == 3 ? 0 : T_EW - T_W>(v, 1, t.b, vary, lane);
+  const auto cx = coef_source<COMPACT, T_EW, MODE == 2 ? 0 : T_NSLOT - T_EW>(v, 0, t.b, varx, lane);
+  double gu = 0.0, gd = 0.0;           // values of the field just above / below the tile
+  if (MODE == 0 && col_on) {
+    if (t.ty > 0) gu = splane[(long)(t.j0 - 1) * v.d.nx + col];
+    else if (v.d.j0 > 0) gu = v.uhalo[0][(long)t.b * v.d.nx + col];                 // row owned by the rank above
+    if (t.ty < v.d.py - 1) gd = splane[(long)(t.j0 + TS) * v.d.nx + col];
+    else if (v.d.j0 + v.d.ny < v.d.gny) gd = v.uhalo[1][(long)t.b * v.d.nx + col];  // row owned by the rank below
+  }
   double e[TS];
   load_cols(splane, t, v.d.nx, lane, e);
-  double gu = 0.0, gd = 0.0;           // values of the field just above / below the tile
-  if (MODE == 3) {
-    // nothing to solve or apply: fall through to the x-elimination
-  } else if (MODE == 0) {
-    if (col_on) {
-      if (t.ty > 0) gu = splane[(long)(t.j0 - 1) * v.d.nx + col];
-      else if (v.d.j0 > 0) gu = v.uhalo[0][(long)t.b * v.d.nx + col];                 // row owned by the rank above
-      if (t.ty < v.d.py - 1) gd = splane[(long)(t.j0 + TS) * v.d.nx + col];
-      else if (v.d.j0 + v.d.ny < v.d.gny) gd = v.uhalo[1][(long)t.b * v.d.nx + col];  // row owned by the rank below
-    }
-  } else {
-    chunk_ghosts<1>(v, t.b, t.ty, col, col_on, gu, gd);
+  if (MODE == 1 || MODE == 2) {
+    ghost_finish<1>(v, t.b, t.ty, col_on, graw, gu, gd);
     e[0] = fma(a, gu, e[0]);
     e[TS - 1] = fma(a, gd, e[TS - 1]);
-    thomas64(e, ty_tab);
+    thomas64(e, cy);
   }
   if (MODE == 2) {
     store_cols(dplane, t, v.d.nx, lane, e);
@@ -208,12 +252,13 @@ __global__ void __launch_bounds__(64) rect_y_kernel(RectView v, const double* sr
   if (col + v.d.i0 == 0) scol += a * v.other_src[0][0];
   if (col + v.d.i0 == v.d.gnx - 1) scol += a * v.other_src[0][1];
   if (MODE != 3) {
-    explicit64(e, gu, gd, ty_tab, col_on ? scol : 0.0);
+    explicit64(e, gu, gd, cy, col_on ? scol : 0.0);
     store_cols(dplane, t, v.d.nx, lane, e);
   }
+  if (QP_ABL & 8) return;
   transpose64(e, lds, lane);
   double yf, yl;
-  dots64(e, table_ptr(v, 0, t.b, chunk_variant(t.tx + v.d.i0 / TS, v.d.gpx)), yf, yl);
+  ends64(e, cx, yf, yl);
   if (lane < t.nr) {
     double* ir = v.iface[0] + (long)t.b * (2 * v.d.px + 2) * v.d.ny;
     ir[(long)(2 * t.tx + 1) * v.d.ny + t.j0 + lane] = yf;
@@ -299,15 +344,27 @@ void build_chunk_table(const DirSpec& s, double a, int p, double* tab, double en
       tab[T_W * TS + k] = 1.0;
     }
   }
+  // elimination slots: forward sweep = the LU pivots again, but padded entries pass the value through; backward sweep =
+  // the UL pivots v_k = 1 / (b_k - a^2 v_{k+1}), zero on padded entries
+  double vnext = 0.0;
+  for (int k = TS - 1; k >= 0; --k) {
+    if (k < len) {
+      const double vk = 1.0 / (bd[k] - (k < len - 1 ? a * a * vnext : 0.0));
+      tab[T_EV * TS + k] = vk;
+      tab[T_EAV * TS + k] = k < len - 1 ? a * vk : 0.0;
+      vnext = vk;
+      tab[T_EW * TS + k] = tab[T_W * TS + k];
+      tab[T_EAWF * TS + k] = tab[T_AWF * TS + k];
+    } else {
+      tab[T_EW * TS + k] = 0.0;
+      tab[T_EAWF * TS + k] = 1.0;
+    }
+  }
   std::vector<double> g(len, 0.0), h(len, 0.0);
   g[0] = 1.0;
   h[len - 1] = 1.0;
   solve_chunk(bd, a, g);
   solve_chunk(bd, a, h);
-  for (int k = 0; k < len; ++k) {
-    tab[T_G * TS + k] = g[k];
-    tab[T_H * TS + k] = h[k];
-  }
   ends[0] = g[0];
   ends[1] = g[len - 1];
   ends[2] = h[0];
@@ -377,17 +434,24 @@ static double reduced_tables(const DirSpec& s, double a, int p0, int Ploc, doubl
 }  // namespace qp
 
 // launches NAME<ARG, STREAM> for the plan's stream mode (0 cached, 2 non-temporal stores, 3 non-temporal both)
-#define QP_LAUNCH_STREAMED(mode, NAME, ARG, ...)                                   \
+#define QP_LAUNCH_STREAMED_C(mode, NAME, ARG, C, ...)                              \
   do {                                                                             \
-    if ((mode) == 0) hipLaunchKernelGGL((NAME<ARG, 0>), __VA_ARGS__);              \
-    else if ((mode) == 2) hipLaunchKernelGGL((NAME<ARG, 2>), __VA_ARGS__);         \
-    else hipLaunchKernelGGL((NAME<ARG, 3>), __VA_ARGS__);                          \
+    if ((mode) == 0) hipLaunchKernelGGL((NAME<ARG, 0, C>), __VA_ARGS__);           \
+    else if ((mode) == 2) hipLaunchKernelGGL((NAME<ARG, 2, C>), __VA_ARGS__);      \
+    else hipLaunchKernelGGL((NAME<ARG, 3, C>), __VA_ARGS__);                       \
+  } while (0)
+// ... and for the plan's table form (compact: constant middle of every slot; otherwise every entry is fetched)
+#define QP_LAUNCH_STREAMED(mode, compact, NAME, ARG, ...)                          \
+  do {                                                                             \
+    if (compact) QP_LAUNCH_STREAMED_C(mode, NAME, ARG, true, __VA_ARGS__);         \
+    else QP_LAUNCH_STREAMED_C(mode, NAME, ARG, false, __VA_ARGS__);                \
   } while (0)
 
 struct qp_adi_rect_plan {
   qp::RectView view;
   double* d_alpha = nullptr;
   double* d_tab = nullptr;
+  double* d_ctab = nullptr;
   double* d_lu[2] = {nullptr, nullptr};
   double* d_icoef[2] = {nullptr, nullptr};
   double* d_iface[2] = {nullptr, nullptr};
@@ -404,6 +468,7 @@ int qp_adi_rect_plan_destroy(qp_adi_rect_plan* plan) {
   if (!plan) return QP_OK;
   (void)hipFree(plan->d_alpha);
   (void)hipFree(plan->d_tab);
+  (void)hipFree(plan->d_ctab);
   for (int d = 0; d < 2; ++d) {
     (void)hipFree(plan->d_lu[d]);
     (void)hipFree(plan->d_icoef[d]);
@@ -451,6 +516,8 @@ int qp_adi_rect_plan_create_block(int32_t ny, int32_t nx, int32_t nfield, double
 
   std::vector<double> alpha(nfield);
   std::vector<double> tab((size_t)2 * nfield * 4 * T_NSLOT * TS, 0.0);
+  bool all_compact = true;
+  std::vector<double> ctab((size_t)2 * nfield * 4 * 2 * CT_PART, 0.0);
   std::vector<double> lu[2], icoef[2];
   double far[2] = {0.0, 0.0};
   for (int d = 0; d < 2; ++d) {
@@ -470,7 +537,10 @@ int qp_adi_rect_plan_create_block(int32_t ny, int32_t nx, int32_t nfield, double
         else if (var == 2) { if (P < 2) continue; p = P - 1; }
         else { if (P != 1) continue; p = 0; }
         double ends[4];
-        build_chunk_table(spec[d], a, p, &tab[((((size_t)d * nfield + b) * 4 + var) * T_NSLOT) * TS], ends);
+        double* tb = &tab[((((size_t)d * nfield + b) * 4 + var) * T_NSLOT) * TS];
+        build_chunk_table(spec[d], a, p, tb, ends);
+        all_compact = all_compact && table_is_compact(tb);
+        build_compact_table(tb, &ctab[(((size_t)d * nfield + b) * 4 + var) * 2 * CT_PART]);
       }
       far[d] = std::max(far[d], reduced_tables(spec[d], a, p0[d], ploc[d],
                                                split[d] ? nullptr : &lu[d][(size_t)b * 5 * 2 * P],
@@ -494,7 +564,9 @@ int qp_adi_rect_plan_create_block(int32_t ny, int32_t nx, int32_t nfield, double
     if (hipMalloc((void**)dptr, count * sizeof(double)) != hipSuccess) return false;
     return hipMemset(*dptr, 0, count * sizeof(double)) == hipSuccess;
   };
-  bool ok = upload(alpha, &plan->d_alpha) && upload(tab, &plan->d_tab);
+  bool ok = upload(alpha, &plan->d_alpha) && upload(tab, &plan->d_tab) && upload(ctab, &plan->d_ctab);
+  v.compact = all_compact ? 1 : 0;
+  if (const char* e = getenv("QPSIM_COMPACT_TABLES")) v.compact = v.compact && atoi(e) != 0;   // 0: force the full form
   for (int d = 0; d < 2 && ok; ++d) {
     const size_t nlines = d == 0 ? ny : nx;
     ok = upload(lu[d], &plan->d_lu[d]) && upload(icoef[d], &plan->d_icoef[d]) &&
@@ -510,6 +582,7 @@ int qp_adi_rect_plan_create_block(int32_t ny, int32_t nx, int32_t nfield, double
   }
   v.alpha = plan->d_alpha;
   v.tab = plan->d_tab;
+  v.ctab = plan->d_ctab;
   for (int d = 0; d < 2; ++d) {
     v.lu[d] = plan->d_lu[d];
     v.icoef[d] = plan->d_icoef[d];
@@ -542,7 +615,7 @@ int qp_adi_rect_phase(qp_adi_rect_plan* plan, int32_t phase, double* u, void* st
   switch (phase) {
     case QP_ADI_ENTRY:
       QP_REQUIRE(u != nullptr, "u is NULL");
-      QP_LAUNCH_STREAMED(v.d.stream, rect_y_kernel, 0, dim3(tiles), dim3(64), 0, stream, v, (const double*)u, w);
+      QP_LAUNCH_STREAMED(v.d.stream, v.compact, rect_y_kernel, 0, dim3(tiles), dim3(64), 0, stream, v, (const double*)u, w);
       break;
     case QP_ADI_REDUCED_X:
       if (!v.decoupled[0])
@@ -550,7 +623,7 @@ int qp_adi_rect_phase(qp_adi_rect_plan* plan, int32_t phase, double* u, void* st
                            stream, v, 0);
       break;
     case QP_ADI_SWEEP_X:
-      QP_LAUNCH_STREAMED(v.d.stream, rect_x_kernel, true, dim3(tiles), dim3(64), 0, stream, v, w);
+      QP_LAUNCH_STREAMED(v.d.stream, v.compact, rect_x_kernel, true, dim3(tiles), dim3(64), 0, stream, v, w);
       break;
     case QP_ADI_REDUCED_Y:
       if (!v.decoupled[1])
@@ -558,11 +631,11 @@ int qp_adi_rect_phase(qp_adi_rect_plan* plan, int32_t phase, double* u, void* st
                            stream, v, 1);
       break;
     case QP_ADI_SWEEP_Y_CARRY:
-      QP_LAUNCH_STREAMED(v.d.stream, rect_y_kernel, 1, dim3(tiles), dim3(64), 0, stream, v, (const double*)w, w);
+      QP_LAUNCH_STREAMED(v.d.stream, v.compact, rect_y_kernel, 1, dim3(tiles), dim3(64), 0, stream, v, (const double*)w, w);
       break;
     case QP_ADI_SWEEP_Y_EXIT:
       QP_REQUIRE(u != nullptr, "u is NULL");
-      QP_LAUNCH_STREAMED(v.d.stream, rect_y_kernel, 2, dim3(tiles), dim3(64), 0, stream, v, (const double*)w, u);
+      QP_LAUNCH_STREAMED(v.d.stream, v.compact, rect_y_kernel, 2, dim3(tiles), dim3(64), 0, stream, v, (const double*)w, u);
       break;
     default:
       set_error("qp_adi_rect_phase: unknown phase %d", phase);
@@ -594,13 +667,13 @@ int qp_adi_rect_solve(qp_adi_rect_plan* plan, double* x, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   const RectView& v = plan->view;
   const unsigned tiles = (unsigned)((long)v.d.nfield * v.d.py * v.d.px);
-  QP_LAUNCH_STREAMED(v.d.stream, rect_y_kernel, 3, dim3(tiles), dim3(64), 0, stream, v, (const double*)x, x);
+  QP_LAUNCH_STREAMED(v.d.stream, v.compact, rect_y_kernel, 3, dim3(tiles), dim3(64), 0, stream, v, (const double*)x, x);
   int rc = qp_adi_rect_phase(plan, QP_ADI_REDUCED_X, x, stream_);
   if (rc) return rc;
-  QP_LAUNCH_STREAMED(v.d.stream, rect_x_kernel, false, dim3(tiles), dim3(64), 0, stream, v, x);
+  QP_LAUNCH_STREAMED(v.d.stream, v.compact, rect_x_kernel, false, dim3(tiles), dim3(64), 0, stream, v, x);
   rc = qp_adi_rect_phase(plan, QP_ADI_REDUCED_Y, x, stream_);
   if (rc) return rc;
-  QP_LAUNCH_STREAMED(v.d.stream, rect_y_kernel, 2, dim3(tiles), dim3(64), 0, stream, v, (const double*)x, x);
+  QP_LAUNCH_STREAMED(v.d.stream, v.compact, rect_y_kernel, 2, dim3(tiles), dim3(64), 0, stream, v, (const double*)x, x);
   return check_launch("qp_adi_rect_solve");
 }
 

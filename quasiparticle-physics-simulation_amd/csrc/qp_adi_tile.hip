@@ -41,6 +41,8 @@ struct TileView {
   int pny, pnx;                 // padded extents of the code planes (py * 64, px * 64)
   const double* alpha;          // [nfield] r D
   const double* tab;            // [nfield][T_NSLOT][TS] interior-chunk tables (clean tiles)
+  int compact;                  // every field's table has the compact form (qp_tile_common.h): clean kernels <..., true>
+  const double* ctab;           // [nfield][2 parts][CT_PART] compact interior-chunk tables (valid when `compact`)
   const uint16_t* code_r;       // [pny][pnx]
   const uint16_t* code_c;       // [pnx][pny]
   const double* bct;            // [nbc][3] (ex, ey, sx + sy)
@@ -225,27 +227,39 @@ __device__ __forceinline__ void ends_general(const double (&e)[TS], const Coef& 
   t = cb;
 }
 
-// Neighbour values of the solved line just outside chunk p of `line`: gl = E_{p-1}, gr = F_{p+1}.
+// Neighbour values of the solved line just outside chunk p of `line`: gl = E_{p-1}, gr = F_{p+1}.  The eight loads are issued
+// by `tile_ghosts_prefetch` at the very start of a kernel (always in bounds: the interface arrays have 2P + 2 rows), the
+// arithmetic happens where the values are needed - see ghost_prefetch in qp_adi_rect.hip.
+struct TileGhostRaw {
+  double y[4], c[4];
+};
+
 template <int DIR>
-__device__ __forceinline__ void tile_ghosts(const TileView& v, int b, int p, long line, bool on, double& gl, double& gr) {
+__device__ __forceinline__ TileGhostRaw tile_ghosts_prefetch(const TileView& v, int b, int p, long line) {
   const int P = DIR == 0 ? v.px : v.py;
   const long nl = DIR == 0 ? v.ny : v.nx;
-  gl = 0.0;
-  gr = 0.0;
-  if (!on) return;
+  if (line > nl - 1) line = nl - 1;
   const long base = (long)b * (2 * P + 2) * nl + line;
   const double* ir = v.iface[DIR] + base;
   const double* cf = v.coef[DIR] + base;
-  if (p > 0) {
-    const double yl = ir[(long)(2 * p) * nl], s = cf[(long)(2 * p) * nl];
-    const double yf = ir[(long)(2 * p + 1) * nl], t = cf[(long)(2 * p + 1) * nl];
-    gl = fma(s, yf, yl) / fma(-s, t, 1.0);
+  TileGhostRaw g;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    g.y[q] = ir[(long)(2 * p + q) * nl];
+    g.c[q] = cf[(long)(2 * p + q) * nl];
   }
-  if (p < P - 1) {
-    const double yl = ir[(long)(2 * p + 2) * nl], s = cf[(long)(2 * p + 2) * nl];
-    const double yf = ir[(long)(2 * p + 3) * nl], t = cf[(long)(2 * p + 3) * nl];
-    gr = fma(t, yl, yf) / fma(-s, t, 1.0);
-  }
+  return g;
+}
+
+template <int DIR>
+__device__ __forceinline__ void tile_ghosts_finish(const TileView& v, int p, bool on, const TileGhostRaw& g, double& gl,
+                                                   double& gr) {
+  const int P = DIR == 0 ? v.px : v.py;
+  gl = 0.0;
+  gr = 0.0;
+  if (p > 0) gl = fma(g.c[0], g.y[1], g.y[0]) / fma(-g.c[0], g.c[1], 1.0);          // (yl + s yf) / (1 - s t)
+  if (p < P - 1) gr = fma(g.c[3], g.y[2], g.y[3]) / fma(-g.c[2], g.c[3], 1.0);      // (yf + t yl) / (1 - s t)
+  if (!on) gl = gr = 0.0;
 }
 
 constexpr int kTileHasBc = 1 << 30;      // tile-list entry: (has_bc << 30) | (ty << 16) | tx
@@ -353,8 +367,23 @@ __device__ __forceinline__ void line_ends(const TileView& v, const TileCoord& t,
   }
 }
 
+// coefficient source of the clean tiles: the field's interior-chunk table in registers, or a part of its compact form
+template <bool COMPACT, int PART>
+__device__ __forceinline__ auto clean_coefs(const TileView& v, int b, int lane, bool clean) {
+  if constexpr (COMPACT) {
+    return CoefCompact{as_const(v.ctab + ((long)b * 2 + PART) * CT_PART)};
+  } else {
+    CoefFull c;
+    if (clean) {
+      if (PART == 0) load_tab<T_W, T_EW - T_W>(v.tab + (long)b * T_NSLOT * TS, lane, c.r);
+      else load_tab<T_EW, T_NSLOT - T_EW>(v.tab + (long)b * T_NSLOT * TS, lane, c.r);
+    }
+    return c;
+  }
+}
+
 // x-kernel: finish the x-solve, [apply (I + a Lx) . + a S], store, chunk-local eliminations along y -> iface[1]
-template <int CLS, bool EXPLICIT, int STREAM>
+template <int CLS, bool EXPLICIT, int STREAM, bool COMPACT = false>
 __global__ void __launch_bounds__(64) tile_x_kernel(TileView v, double* __restrict__ buf) {
   __shared__ double lds[LDS_DOUBLES];
   extern __shared__ double bct[];
@@ -365,19 +394,21 @@ __global__ void __launch_bounds__(64) tile_x_kernel(TileView v, double* __restri
   const long ncell = (long)v.ny * v.nx;
   double* plane = buf + (long)t.b * ncell;
   const double a = as_const(v.alpha)[t.b];
-  const ctab_t tab = as_const(v.tab + (long)t.b * T_NSLOT * TS);
+  const TileGhostRaw graw = tile_ghosts_prefetch<0>(v, t.b, t.tx, t.j0 + lane);
+  const auto csolve = clean_coefs<COMPACT, 0>(v, t.b, lane, CLS == 0);
+  const auto cends = clean_coefs<COMPACT, 1>(v, t.b, lane, CLS == 0);
   double e[TS];
   load_cols(plane, t, v.nx, lane, e);
   transpose64(e, lds, lane);
   double gl, gr;
-  tile_ghosts<0>(v, t.b, t.tx, t.j0 + lane, lane < t.nr, gl, gr);
+  tile_ghosts_finish<0>(v, t.tx, lane < t.nr, graw, gl, gr);
   if (CLS != 0) {
     line_work<CLS, 0, true, EXPLICIT>(v, t, lane, has_bc, bct, a, e, gl, gr);
   } else {
     e[0] = fma(a, gl, e[0]);
     e[TS - 1] = fma(a, gr, e[TS - 1]);
-    thomas64(e, tab);
-    if (EXPLICIT) explicit64(e, gl, gr, tab, 0.0);
+    thomas64(e, csolve);
+    if (EXPLICIT) explicit64(e, gl, gr, csolve, 0.0);
   }
   transpose64(e, lds, lane);
   store_cols(plane, t, v.nx, lane, e);
@@ -386,7 +417,7 @@ __global__ void __launch_bounds__(64) tile_x_kernel(TileView v, double* __restri
     double s, tt, w0, w1;
     line_ends<CLS, 1>(v, t, lane, has_bc, bct, a, e, yf, yl, s, tt, w0, w1);
   } else {
-    dots64(e, tab, yf, yl);
+    ends64(e, cends, yf, yl);
   }
   if (lane < t.nc) {
     double* ir = v.iface[1] + (long)t.b * (2 * v.py + 2) * v.nx;
@@ -398,7 +429,7 @@ __global__ void __launch_bounds__(64) tile_x_kernel(TileView v, double* __restri
 // y-kernel.  MODE 0 (entry): src = u -> rhs1 = (I + a Ly) u + a S;  MODE 1 (carry): y-solve, rhs1' of the next step;
 //            MODE 2 (exit): y-solve, dst = u';  MODE 3 (reduce): only the x-eliminations of src (nothing stored).
 //            MODE 0, 1, 3 end with the chunk-local eliminations along x -> iface[0]
-template <int CLS, int MODE, int STREAM>
+template <int CLS, int MODE, int STREAM, bool COMPACT = false>
 __global__ void __launch_bounds__(64) tile_y_kernel(TileView v, const double* src, double* dst) {   // src may alias dst
   __shared__ double lds[LDS_DOUBLES];
   extern __shared__ double bct[];
@@ -410,18 +441,20 @@ __global__ void __launch_bounds__(64) tile_y_kernel(TileView v, const double* sr
   const double* splane = src + (long)t.b * ncell;
   double* dplane = dst + (long)t.b * ncell;
   const double a = as_const(v.alpha)[t.b];
-  const ctab_t tab = as_const(v.tab + (long)t.b * T_NSLOT * TS);
   const int col = t.i0 + lane;
   const bool col_on = lane < t.nc;
-  double e[TS];
-  load_cols(splane, t, v.nx, lane, e);
+  TileGhostRaw graw;
+  if (MODE == 1 || MODE == 2) graw = tile_ghosts_prefetch<1>(v, t.b, t.ty, col);
+  const auto csolve = clean_coefs<COMPACT, 0>(v, t.b, lane, CLS == 0 && MODE != 3);
+  const auto cends = clean_coefs<COMPACT, 1>(v, t.b, lane, CLS == 0 && MODE != 2);
   double gu = 0.0, gd = 0.0;
   if (MODE == 0) {
     if (col_on && t.ty > 0) gu = splane[(long)(t.j0 - 1) * v.nx + col];
     if (col_on && t.j0 + TS < v.ny) gd = splane[(long)(t.j0 + TS) * v.nx + col];
-  } else if (MODE != 3) {
-    tile_ghosts<1>(v, t.b, t.ty, col, col_on, gu, gd);
   }
+  double e[TS];
+  load_cols(splane, t, v.nx, lane, e);
+  if (MODE == 1 || MODE == 2) tile_ghosts_finish<1>(v, t.ty, col_on, graw, gu, gd);
   if (CLS != 0) {
     if (MODE == 0) line_work<CLS, 1, false, true>(v, t, lane, has_bc, bct, a, e, gu, gd);
     if (MODE == 1) line_work<CLS, 1, true, true>(v, t, lane, has_bc, bct, a, e, gu, gd);
@@ -430,9 +463,9 @@ __global__ void __launch_bounds__(64) tile_y_kernel(TileView v, const double* sr
     if (MODE == 1 || MODE == 2) {
       e[0] = fma(a, gu, e[0]);
       e[TS - 1] = fma(a, gd, e[TS - 1]);
-      thomas64(e, tab);
+      thomas64(e, csolve);
     }
-    if (MODE == 0 || MODE == 1) explicit64(e, gu, gd, tab, 0.0);
+    if (MODE == 0 || MODE == 1) explicit64(e, gu, gd, csolve, 0.0);
   }
   if (MODE != 3) store_cols(dplane, t, v.nx, lane, e);
   if (MODE == 2) return;
@@ -442,7 +475,7 @@ __global__ void __launch_bounds__(64) tile_y_kernel(TileView v, const double* sr
     double s, tt, w0, w1;
     line_ends<CLS, 0>(v, t, lane, has_bc, bct, a, e, yf, yl, s, tt, w0, w1);
   } else {
-    dots64(e, tab, yf, yl);
+    ends64(e, cends, yf, yl);
   }
   if (lane < t.nr) {
     double* ir = v.iface[0] + (long)t.b * (2 * v.px + 2) * v.ny;
@@ -631,11 +664,15 @@ static int tile_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, co
   }
   // interior-chunk tables of the rectangle path (chunk 1 of a 3-chunk line; end faces irrelevant)
   std::vector<double> alpha(nfield), tab((size_t)nfield * T_NSLOT * TS);
+  bool all_compact = true;
+  std::vector<double> ctab((size_t)nfield * 2 * CT_PART, 0.0);
   const DirSpec spec{3 * TS, 3, 0.0, 0.0, 0.0, 0.0};
   for (int b = 0; b < nfield && !var; ++b) {
     alpha[b] = r * dcoef_host[b];
     double ends[4];
     build_chunk_table(spec, alpha[b], 1, &tab[(size_t)b * T_NSLOT * TS], ends);
+    all_compact = all_compact && table_is_compact(&tab[(size_t)b * T_NSLOT * TS]);
+    build_compact_table(&tab[(size_t)b * T_NSLOT * TS], &ctab[(size_t)b * 2 * CT_PART]);
   }
 
   auto* plan = new qp_adi_tile_plan();
@@ -667,6 +704,9 @@ static int tile_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, co
   };
   v.alpha = (const double*)upload(alpha.data(), alpha.size() * sizeof(double));
   v.tab = (const double*)upload(tab.data(), tab.size() * sizeof(double));
+  v.ctab = (const double*)upload(ctab.data(), ctab.size() * sizeof(double));
+  v.compact = (all_compact && !var) ? 1 : 0;
+  if (const char* e = getenv("QPSIM_COMPACT_TABLES")) v.compact = v.compact && atoi(e) != 0;
   v.code_r = (const uint16_t*)upload(code_r.data(), code_r.size() * sizeof(uint16_t));
   v.code_c = (const uint16_t*)upload(code_c.data(), code_c.size() * sizeof(uint16_t));
   v.bct = (const double*)upload(bct.data(), bct.size() * sizeof(double));
@@ -756,9 +796,15 @@ static void launch_x(const qp_adi_tile_plan* plan, double* buf, hipStream_t stre
   const TileView& v = plan->view;
   if (v.ntiles[0] > 0) {
     const dim3 grid((unsigned)((long)v.ntiles[0] * v.nfield));
-    if (v.stream == 0) hipLaunchKernelGGL((tile_x_kernel<0, EXPLICIT, 0>), grid, dim3(64), 0, stream, v, buf);
-    else if (v.stream == 2) hipLaunchKernelGGL((tile_x_kernel<0, EXPLICIT, 2>), grid, dim3(64), 0, stream, v, buf);
-    else hipLaunchKernelGGL((tile_x_kernel<0, EXPLICIT, 3>), grid, dim3(64), 0, stream, v, buf);
+    if (v.compact) {
+      if (v.stream == 0) hipLaunchKernelGGL((tile_x_kernel<0, EXPLICIT, 0, true>), grid, dim3(64), 0, stream, v, buf);
+      else if (v.stream == 2) hipLaunchKernelGGL((tile_x_kernel<0, EXPLICIT, 2, true>), grid, dim3(64), 0, stream, v, buf);
+      else hipLaunchKernelGGL((tile_x_kernel<0, EXPLICIT, 3, true>), grid, dim3(64), 0, stream, v, buf);
+    } else {
+      if (v.stream == 0) hipLaunchKernelGGL((tile_x_kernel<0, EXPLICIT, 0>), grid, dim3(64), 0, stream, v, buf);
+      else if (v.stream == 2) hipLaunchKernelGGL((tile_x_kernel<0, EXPLICIT, 2>), grid, dim3(64), 0, stream, v, buf);
+      else hipLaunchKernelGGL((tile_x_kernel<0, EXPLICIT, 3>), grid, dim3(64), 0, stream, v, buf);
+    }
   }
   if (v.ntiles[1] > 0 && !v.var)
     hipLaunchKernelGGL((tile_x_kernel<1, EXPLICIT, -1>), dim3((unsigned)((long)v.ntiles[1] * v.nfield)), dim3(64),
@@ -773,9 +819,15 @@ static void launch_y(const qp_adi_tile_plan* plan, const double* src, double* ds
   const TileView& v = plan->view;
   if (v.ntiles[0] > 0) {
     const dim3 grid((unsigned)((long)v.ntiles[0] * v.nfield));
-    if (v.stream == 0) hipLaunchKernelGGL((tile_y_kernel<0, MODE, 0>), grid, dim3(64), 0, stream, v, src, dst);
-    else if (v.stream == 2) hipLaunchKernelGGL((tile_y_kernel<0, MODE, 2>), grid, dim3(64), 0, stream, v, src, dst);
-    else hipLaunchKernelGGL((tile_y_kernel<0, MODE, 3>), grid, dim3(64), 0, stream, v, src, dst);
+    if (v.compact) {
+      if (v.stream == 0) hipLaunchKernelGGL((tile_y_kernel<0, MODE, 0, true>), grid, dim3(64), 0, stream, v, src, dst);
+      else if (v.stream == 2) hipLaunchKernelGGL((tile_y_kernel<0, MODE, 2, true>), grid, dim3(64), 0, stream, v, src, dst);
+      else hipLaunchKernelGGL((tile_y_kernel<0, MODE, 3, true>), grid, dim3(64), 0, stream, v, src, dst);
+    } else {
+      if (v.stream == 0) hipLaunchKernelGGL((tile_y_kernel<0, MODE, 0>), grid, dim3(64), 0, stream, v, src, dst);
+      else if (v.stream == 2) hipLaunchKernelGGL((tile_y_kernel<0, MODE, 2>), grid, dim3(64), 0, stream, v, src, dst);
+      else hipLaunchKernelGGL((tile_y_kernel<0, MODE, 3>), grid, dim3(64), 0, stream, v, src, dst);
+    }
   }
   if (v.ntiles[1] > 0 && !v.var)
     hipLaunchKernelGGL((tile_y_kernel<1, MODE, -1>), dim3((unsigned)((long)v.ntiles[1] * v.nfield)), dim3(64),

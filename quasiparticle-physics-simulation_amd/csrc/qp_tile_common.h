@@ -17,14 +17,57 @@ constexpr size_t kStreamBytes = (size_t)192 << 20;
 // bit 0: non-temporal loads, bit 1: non-temporal stores; QPSIM_STREAM_MODE=0..3 overrides the size rule (tuning knob)
 inline int stream_mode(size_t plane_set_bytes) {
   if (const char* e = getenv("QPSIM_STREAM_MODE")) return atoi(e) & 3;
-  // measured on MI355X (fraction of 8 TB/s, cached / NT stores / NT both): 4096^2 (128 MiB) 0.62 / 0.59 / 0.60;
-  // 8192^2 (512 MiB) 0.61 / 0.735 / 0.69; 16384^2 (2 GiB) 0.64 / 0.67 / 0.71
-  if (plane_set_bytes > 4 * kStreamBytes) return 3;
+  // measured on MI355X, round 2 kernels (sweep time in us, cached / NT stores / NT both): 5760^2 (253 MiB) 91.7 / 89.8 / 97.2;
+  // 4096^2 x 2 (256 MiB) 88.5 / 89.5 / 93.5; 8192^2 (512 MiB) 211 / 206 / 188; 4096^2 x 4 (512 MiB) 200 / 190 / 177;
+  // 11520^2 (1 GiB) 407 / 410 / 376: once the carried planes no longer fit the 256 MiB Infinity Cache both directions
+  // should bypass it
+  if (plane_set_bytes > 2 * kStreamBytes) return 3;
   return plane_set_bytes > kStreamBytes ? 2 : 0;      // (an environment override of 1 is served by the kernels of 3)
 }
 
-// table slots per (direction, field, chunk variant); each slot is TS doubles
-enum { T_W = 0, T_AWF, T_AWB, T_CM, T_C0, T_CP, T_SRC, T_G, T_H, T_NSLOT };
+// table slots per (direction, field, chunk variant); each slot is TS doubles.  T_W..T_SRC drive the solve and the explicit
+// operator along the chunk; T_EW..T_EAV the two eliminations that give the first / last entry of A_p^-1 d (forward sweep
+// with the LU pivots, backward sweep with the UL pivots) for the reduced right-hand sides of the other direction.
+enum { T_W = 0, T_AWF, T_AWB, T_CM, T_C0, T_CP, T_SRC, T_EW, T_EAWF, T_EV, T_EAV, T_NSLOT };
+
+// Compact form of a table: the pivots of a chunk converge to their fixed point within a dozen cells of its end (rate rho^2
+// per cell) and the explicit-operator coefficients differ from (a, 1 - 2a, a, 0) only in the cells that touch a wall, so for
+// every full-length chunk each slot is CONSTANT on [pre, TS - suf): a short prefix / suffix of distinct entries and one
+// value for the middle.  The plan checks that bit for bit per table (`table_is_compact`); kernels then feed the middle of
+// every dependent chain from one SGPR pair and fetch only the prefix / suffix entries.
+constexpr int kTabMid = TS / 2;
+__host__ __device__ constexpr int slot_pre(int slot) {
+  return (slot == T_W || slot == T_AWF || slot == T_AWB || slot == T_EW || slot == T_EAWF) ? 16 : 1;
+}
+__host__ __device__ constexpr int slot_suf(int slot) { return (slot == T_EV || slot == T_EAV) ? 16 : 1; }
+inline bool table_is_compact(const double* tab) {
+  for (int q = 0; q < T_NSLOT; ++q)
+    for (int k = slot_pre(q); k < TS - slot_suf(q); ++k)
+      if (tab[q * TS + k] != tab[q * TS + kTabMid]) return false;
+  return true;
+}
+// Compact table = two parts of CT_PART doubles (solve slots T_W..T_SRC, elimination slots T_EW..T_EAV): the 16-entry
+// prefixes / suffixes, then per slot its middle value, its last (or first) entry.  cidx maps (slot, k) into its part.
+constexpr int CT_PART = 72;
+__host__ __device__ constexpr int cidx(int slot, int k) {
+  if (slot < T_EW) {
+    if (slot <= T_AWB && k < 16) return slot * 16 + k;                  // W, AWF, AWB prefixes: 0..47
+    if (k == TS - 1) return 56 + slot;                                  // last entry of every solve slot: 56..62
+    if (slot >= T_CM && k == 0) return 64 + (slot - T_CM);              // first entry of the explicit slots: 64..67
+    return 48 + slot;                                                   // middle: 48..54
+  }
+  const int q = slot - T_EW;                                            // 0 EW, 1 EAWF, 2 EV, 3 EAV
+  if (q < 2 && k < 16) return q * 16 + k;                               // forward prefixes: 0..31
+  if (q >= 2 && k >= TS - 16) return q * 16 + (k - (TS - 16));          // backward suffixes: 32..63
+  if (q < 2 && k == TS - 1) return 68 + q;                              // EW, EAWF last: 68, 69
+  if (q >= 2 && k == 0) return 68 + q;                                  // EV, EAV first: 70, 71
+  return 64 + q;                                                        // middle: 64..67
+}
+inline void build_compact_table(const double* tab, double* ct) {       // ct[2][CT_PART]
+  for (int i = 0; i < 2 * CT_PART; ++i) ct[i] = 0.0;
+  for (int q = 0; q < T_NSLOT; ++q)
+    for (int k = 0; k < TS; ++k) ct[(q < T_EW ? 0 : CT_PART) + cidx(q, k)] = tab[q * TS + k];
+}
 
 // Tables are written once at plan creation and never by a kernel: read them through the constant address space so
 // that wave-uniform accesses become scalar loads (s_load) and the values feed the FMAs straight from SGPRs.
@@ -38,44 +81,103 @@ __device__ __forceinline__ ctab_t as_const(const double* p) {
   return (ctab_t)(((unsigned long long)hi << 32) | lo);
 }
 
+#ifndef QP_ABL
+#define QP_ABL 0      // timing-only ablation builds (tools/ablate.sh): results are wrong, only the clock matters
+#endif
+
+// Where the solves get coefficient k of a slot from.  The chains need it as a wave-uniform operand at step k.
+//  * CoefCompact (every table of the plan has the compact form - all grids whose extents are multiples of 64 with
+//    r D <~ 1.5): a 576-byte scalar table per part; the middle of every chain runs on one SGPR pair per slot and only the
+//    16-entry prefixes / suffixes are fetched (a handful of s_load_dwordx16, issued while the tile rows are in flight).
+//  * CoefFull: lane k loads entry k of every slot once (one coalesced 512 B load per slot, ahead of the tile rows) and step
+//    k fetches it with v_readlane into an SGPR pair - two VALU instructions per coefficient, no memory latency in the
+//    chain.  (Streaming full tables through scalar loads put a scalar-memory round trip in front of every few steps:
+//    16 % of the 4096^2 sweep and 34 % of the 2048^2 sweep were spent in those waits.)
+struct TabRegs {
+  double s[T_NSLOT];
+};
+
+template <int FIRST, int COUNT>
+__device__ __forceinline__ void load_tab(const double* __restrict__ tab, int lane, TabRegs& r) {
+#pragma unroll
+  for (int q = FIRST; q < FIRST + COUNT; ++q) r.s[q] = tab[q * TS + lane];
+}
+
+__device__ __forceinline__ double tab_at(const TabRegs& r, int slot, int k) {
+  // The empty volatile asm "redefines" the source at this point of the instruction stream: readlanes are pure, and
+  // without it the scheduler hoists hundreds of them to the top of the unrolled chains, runs out of SGPRs and spills
+  // them into VGPR lanes.  Volatile asms keep their relative order.
+  double src = r.s[slot];
+  asm volatile("" : "+v"(src));
+  const unsigned long long b = (unsigned long long)__double_as_longlong(src);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, k);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), k);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+struct CoefFull {
+  TabRegs r;
+  __device__ __forceinline__ double at(int slot, int k) const {
+    if (QP_ABL & 2) return 0.1 + 0.001 * slot;
+    return tab_at(r, slot, k);
+  }
+};
+
+struct CoefCompact {
+  ctab_t part;      // the part (solve or elimination) of the compact table this kernel phase reads
+  __device__ __forceinline__ double at(int slot, int k) const {
+    if (QP_ABL & 2) return 0.1 + 0.001 * slot;
+    return part[cidx(slot, k)];
+  }
+};
+
 // Thomas solve of one chunk held in registers; padded entries (k >= chunk length) carry w = 1, aw = 0.
-__device__ __forceinline__ void thomas64(double (&e)[TS], ctab_t t) {
+template <class Coef>
+__device__ __forceinline__ void thomas64(double (&e)[TS], const Coef& t) {
+  if (QP_ABL & 16) return;
   double dp = 0.0;
 #pragma unroll
   for (int k = 0; k < TS; ++k) {
-    dp = fma(t[T_AWF * TS + k], dp, e[k] * t[T_W * TS + k]);
+    dp = fma(t.at(T_AWF, k), dp, e[k] * t.at(T_W, k));
     e[k] = dp;
   }
   double x = 0.0;
 #pragma unroll
   for (int k = TS - 1; k >= 0; --k) {
-    x = fma(t[T_AWB * TS + k], x, e[k]);
+    x = fma(t.at(T_AWB, k), x, e[k]);
     e[k] = x;
   }
 }
 
 // e <- (I + a L) e + a s along the chunk, with neighbour values gl / gr beyond its ends, plus `extra` on valid cells.
-__device__ __forceinline__ void explicit64(double (&e)[TS], double gl, double gr, ctab_t t, double extra) {
+template <class Coef>
+__device__ __forceinline__ void explicit64(double (&e)[TS], double gl, double gr, const Coef& t, double extra) {
+  if (QP_ABL & 32) return;
   double prev = gl;
 #pragma unroll
   for (int k = 0; k < TS; ++k) {
     const double cur = e[k];
     const double nxt = (k + 1 < TS) ? e[k + 1] : gr;
-    // `extra` also lands on padded cells (k >= chunk length); those are never stored and meet zero weights in dots64
-    e[k] = fma(t[T_CM * TS + k], prev, fma(t[T_CP * TS + k], nxt, fma(t[T_C0 * TS + k], cur, t[T_SRC * TS + k] + extra)));
+    // `extra` also lands on padded cells (k >= chunk length); those are never stored and are skipped by ends64
+    e[k] = fma(t.at(T_CM, k), prev, fma(t.at(T_CP, k), nxt, fma(t.at(T_C0, k), cur, t.at(T_SRC, k) + extra)));
     prev = cur;
   }
 }
 
-__device__ __forceinline__ void dots64(const double (&e)[TS], ctab_t t, double& yf, double& yl) {
-  double a0 = 0.0, a1 = 0.0;
+// First / last entry of A_p^-1 e (the reduced right-hand sides of the chunk): yl is where the forward elimination ends,
+// yf where the backward one does.  Padded entries pass the forward value through (ew = 0, eawf = 1) and keep the backward
+// one at zero until the last valid cell (ev = eav = 0), so whatever sits in padded cells is never looked at.
+template <class Coef>
+__device__ __forceinline__ void ends64(const double (&e)[TS], const Coef& t, double& yf, double& yl) {
+  double dp = 0.0, bp = 0.0;
 #pragma unroll
   for (int k = 0; k < TS; ++k) {
-    a0 = fma(t[T_G * TS + k], e[k], a0);
-    a1 = fma(t[T_H * TS + k], e[k], a1);
+    const int j = TS - 1 - k;
+    dp = fma(t.at(T_EAWF, k), dp, e[k] * t.at(T_EW, k));
+    bp = fma(t.at(T_EAV, j), bp, e[j] * t.at(T_EV, j));
   }
-  yf = a0;
-  yl = a1;
+  yf = bp;
+  yl = dp;
 }
 
 // In-place transpose of the 64 x 64 tile distributed as v[j] on lane i  ->  v[i] on lane j (its own inverse:
@@ -99,6 +201,7 @@ __device__ __forceinline__ void swap_half_waves(double& lo_reg, double& hi_reg) 
 }
 
 __device__ __forceinline__ void transpose64(double (&v)[TS], double* lds, int lane) {
+  if (QP_ABL & 4) return;
   const int l = lane & 31;
   double* blk = lds + (lane >> 5) * (HB * HP);
 #pragma unroll

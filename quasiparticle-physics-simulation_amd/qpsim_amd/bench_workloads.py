@@ -19,8 +19,8 @@ from .models import BoundaryCondition
 HBM_PEAK_GBS = 8000.0
 
 
-def _rect_engine(N: int, device):
-    mask = np.ones((N, N), dtype=bool)
+def _rect_engine(N: int, device, nx: int | None = None):
+    mask = np.ones((N, N if nx is None else nx), dtype=bool)
     edges = extract_edge_segments(mask)
     bcs = {e.edge_id: BoundaryCondition("reflective") for e in edges}
     return Engine(compile_geometry(mask, edges, bcs, 1.0), device=device)
@@ -125,11 +125,13 @@ class CoupledWorkload:
     """
 
     def __init__(self, N, device, *, ne=12, recombination=True, scattering=True, dynamic_phonons=True, label="",
-                 members=1, fmax=3.0):
+                 members=1, fmax=3.0, nx=None, init_occupation=None):
         """``members`` independent N x N problems are batched: planes are laid out [bin][member][cell], so the ADI plan
-        sees NE*members fields of N x N and the collision kernel sees members*N*N pixels (no coupling between members)."""
+        sees NE*members fields of N x N and the collision kernel sees members*N*N pixels (no coupling between members).
+        ``nx``: N x nx rectangle instead of a square; ``init_occupation``: device tensor [N*nx] replacing the seeded field."""
         self.N, self.nfield, self.ne, self.members = N, ne * members, ne, members
-        self.eng = eng = _rect_engine(N, device)
+        NX = N if nx is None else int(nx)
+        self.eng = eng = _rect_engine(N, device, NX)
         torch = eng.torch
         gap, D0, dt = 180.0, 6.0, 0.1
         self.dt = dt
@@ -143,25 +145,28 @@ class CoupledWorkload:
         self.tab = eng.make_collision_tables(kr, ks, rho[None], idx_d, idx_s, sg)
         self.en_r, self.en_s, self.upd = recombination, scattering, dynamic_phonons
         w = rho / (np.sum(rho) * dE)
-        npix = members * N * N
+        npix = members * N * NX
         self.npix = npix
-        init = np.concatenate([1e-4 * (1.0 + np.random.default_rng(1000 + m if members > 1 else 0).random(N * N))
-                               for m in range(members)])
-        self.state = torch.as_tensor(w[:, None] * init[None, :], device=eng.device)     # [NE][members*ncell]
+        if init_occupation is None:
+            init = np.concatenate([1e-4 * (1.0 + np.random.default_rng(1000 + m if members > 1 else 0).random(N * NX))
+                                   for m in range(members)])
+            self.state = torch.as_tensor(w[:, None] * init[None, :], device=eng.device)     # [NE][members*ncell]
+        else:
+            self.state = torch.as_tensor(w, device=eng.device)[:, None] * init_occupation.reshape(1, -1)
         self.alt = torch.empty_like(self.state)
         nph = T.thermal_phonon_occupation(om, 0.1)
         self.phonon = torch.as_tensor(np.repeat(nph[:, None], npix, axis=1), device=eng.device)
         self.coll_flags = torch.full((npix,), 16, dtype=torch.uint8, device=eng.device)   # every pixel interior
         self.op = DiffusionOperator(eng, ne * members, dt,
                                     dcoef=np.repeat(T.diffusion_coefficients(E, gap, D0), members))
-        self.grid = [N, N]
-        self.cell_updates_per_step = float(N) * N * ne * members
+        self.grid = [N, NX]
+        self.cell_updates_per_step = float(N) * NX * ne * members
         planes_rw = (ne + self.nw) + (ne + (self.nw if dynamic_phonons else 0))
         self.coll_bytes_per_call = 8.0 * planes_rw * npix
         self.bytes_per_step = 48.0 * self.cell_updates_per_step + 2 * self.coll_bytes_per_call
         self.path = f"rect-tiled ADI + {self.tab['kernel']} collision kernel"
         ens = f"{members} independent members of " if members > 1 else ""
-        self.description = (f"{label}{ens}{N}x{N} fp64, NE={ne}, Nw={self.nw}: Strang C(dt/2) D(dt) C(dt/2) + Pauli guard per step; "
+        self.description = (f"{label}{ens}{N}x{NX} fp64, NE={ne}, Nw={self.nw}: Strang C(dt/2) D(dt) C(dt/2) + Pauli guard per step; "
                             f"recombination={'on' if recombination else 'off'}, scattering={'on' if scattering else 'off'}, "
                             f"phonons {'dynamic' if dynamic_phonons else 'frozen'}; reflective walls, D0=6 dt=0.1 dx=1")
         self.max_occ = 0.0
@@ -298,9 +303,114 @@ class DecomposedADIWorkload:
                 "note": "per-rank sweep time including the neighbour exchange that follows it"}
 
 
+def _global_field(torch, j0: int, i0: int, ny: int, nx: int, device):
+    """Deterministic synthetic field 1e-4 (1 + hash(j, i)) evaluated on global coordinates, so that every rank fills its own
+    cells AND its halos consistently without talking to anybody."""
+    j = torch.arange(j0, j0 + ny, dtype=torch.float64, device=device)[:, None]
+    i = torch.arange(i0, i0 + nx, dtype=torch.float64, device=device)[None, :]
+    h = torch.sin(j * 12.9898 + i * 78.233) * 43758.5453
+    return 1e-4 * (1.0 + (h - torch.floor(h)))
+
+
+class OverlapDecomposedWorkload:
+    """BASELINE configs[4] (8192 x 8192 on 2 x 4 GPUs) with the overlapped-halo decomposition: every rank runs the
+    single-GPU kernels on its block + 64-cell halos and the halos are refreshed over RCCL once every S steps
+    (``distributed.halo_steps_bound``); ``coupled=True`` adds the collision half-steps (full physics, NE = 12) on the
+    decomposed grid.  Strong scaling: the global grid is fixed."""
+
+    def __init__(self, N: int, device, coupled: bool = False, steps_per_exchange=None):
+        import torch.distributed as dist
+        from .distributed import BlockTopology, HipOverlapBlock, OverlapBlock, TorchDistTransport, choose_process_grid
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        py, px = choose_process_grid(self.world, N, N)
+        self.topo = BlockTopology(N, N, py, px, rank)
+        self.transport = TorchDistTransport() if self.world > 1 else None
+        self.coupled = coupled
+        j0, i0, ny, nx = self.topo.block
+        if not coupled:
+            self.block = HipOverlapBlock(self.topo, 1.0, 0.1, [6.0], [0.0] * 4, [0.0] * 4, device=device,
+                                         steps_per_exchange=steps_per_exchange)
+            torch = self.block.torch
+            ej, ei = self.block.ext_origin()
+            self.block.u.copy_(_global_field(torch, ej, ei, self.block.ey, self.block.ex, self.block.device)[None])
+            self.nfield, ne = 1, 1
+            self.device = self.block.device
+        else:
+            import torch
+            ne = 12
+            E, _ = T.build_energy_grid(180.0, 1.0, 3.0, ne)
+            dmax = float(np.max(T.diffusion_coefficients(E, 180.0, 6.0)))
+            # collision half-steps between the sweeps: same locality argument, half the cadence for margin
+            probe = OverlapBlock(self.topo, ne, 0.5 * 0.1 * dmax, steps_per_exchange=steps_per_exchange)
+            spe = max(1, probe.steps_per_exchange // 2)
+            dev = torch.device(device)
+            ej, ei = probe.ext_origin()
+            self.inner = CoupledWorkload(probe.ey, dev, nx=probe.ex, init_occupation=_global_field(
+                torch, ej, ei, probe.ey, probe.ex, dev).reshape(-1))
+            outer = self
+
+            class _Block(OverlapBlock):
+                @property
+                def u(self):       # the collision calls swap state / alt: always the current quasiparticle planes
+                    return outer.inner.state.view(ne, self.ey, self.ex)
+
+                @u.setter
+                def u(self, value):
+                    pass
+
+                def advance(self, nsteps):
+                    outer.inner.run(nsteps)
+
+            self.block = _Block(self.topo, ne, 0.5 * 0.1 * dmax, steps_per_exchange=spe)
+            self.nfield = ne
+            self.device = dev
+        self.N, self.grid = N, [N, N]
+        self.cell_updates_per_step = float(N) * N * ne / self.world        # own cells only; bench multiplies by world
+        self.bytes_per_step = 32.0 * self.cell_updates_per_step
+        b = self.block
+        self.halo_overhead = b.ey * b.ex / float(ny * nx) - 1.0
+        self.path = (f"overlapped-halo decomposition {py}x{px}: block {ny}x{nx} + halo {b.halo} = {b.ey}x{b.ex} per rank "
+                     f"(+{100 * self.halo_overhead:.1f} % cells), halo refresh every {b.steps_per_exchange} steps "
+                     f"(x strips then y strips, point-to-point over RCCL), rect-tiled partition ADI"
+                     + (" + register collision kernel" if coupled else ""))
+        self.description = (f"{N}x{N} fp64 " + ("coupled step C(dt/2) D(dt) C(dt/2), NE=12, " if coupled else "CN-ADI step, ")
+                            + f"domain-decomposed {py}x{px} (one block per GPU), reflective walls, D=6 dt=0.1 dx=1")
+        self.scaling = "strong"
+
+    def run(self, k: int, exchange: bool = True):
+        from .distributed import overlap_adi_steps
+        overlap_adi_steps(self.block, self.transport, k, exchange=exchange)
+
+    def roofline(self, nrep: int) -> dict:
+        torch = self.block.torch if not self.coupled else self.inner.eng.torch
+        dev = self.device
+        if self.coupled:
+            return self.inner.roofline(nrep)
+        k = max(1, min(10, self.block.steps_per_exchange))
+        self.block.advance(2)
+        torch.cuda.synchronize(dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream(dev))
+        for _ in range(nrep):
+            self.block.advance(k)
+        ev1.record(torch.cuda.current_stream(dev))
+        torch.cuda.synchronize(dev)
+        per_sweep = ev0.elapsed_time(ev1) * 1e-3 / (nrep * (2 * k + 1))
+        bytes_per_launch = 16.0 * self.block.ey * self.block.ex
+        achieved = bytes_per_launch / per_sweep / 1e9
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "kernel": "rect_x_kernel / rect_y_kernel on the extended local block (rank 0)",
+                "bytes_per_launch": bytes_per_launch, "avg_launch_us": per_sweep * 1e6,
+                "note": "per-rank sweep on block + halos; the halo cells are redundant work and are NOT counted in `value`"}
+
+
 def build(name: str, device):
-    m = re.fullmatch(r"dd(\d+)", name)
-    if m:
+    m = re.fullmatch(r"dd(\d+)(c?)", name)
+    if m:   # dd<N>: scalar field, overlapped-halo decomposition; dd<N>c: coupled (collisions + ADI, NE = 12)
+        return OverlapDecomposedWorkload(int(m.group(1)), device, coupled=bool(m.group(2)))
+    m = re.fullmatch(r"ddx(\d+)", name)
+    if m:   # ddx<N>: exact interface exchange after every sweep (qp_adi_rect_phase), the scheme for stiff steps
         return DecomposedADIWorkload(int(m.group(1)), device)
     m = re.fullmatch(r"adi(\d+)", name)
     if m:

@@ -285,3 +285,219 @@ class HipBlockBackend:
     def phase(self, ph: int) -> None:
         self._hip.check(self.lib.qp_adi_rect_phase(self.plan.handle, ph, int(self.u.data_ptr()), self.stream),
                         "qp_adi_rect_phase")
+
+
+# ------------------------------------------------------------------------------------------------------------------ #
+# Overlapped-halo decomposition: exchange once every S steps instead of twice per step
+# ------------------------------------------------------------------------------------------------------------------ #
+# The line solves of the ADI step are global, but their Green's function decays like rho^|distance| (rho ~ 0.2 for
+# r D = 0.3, < 0.46 in the whole decoupled regime r D < 1.5).  A block that carries a halo of H cells of its neighbours'
+# data and cuts the lines at the OUTER edge of that halo therefore computes its OWN cells with an error ~ rho^H per step
+# (1e-45 for H = 64, r D = 0.3) - the same "below fp64 significance" argument by which the tiled kernels drop the far
+# couplings between 64-cell chunks (qp_tile_common.h, kFarCouplingDrop = 1e-22).  The cut error creeps inwards by a few
+# cells per step, so the halo stays good for S steps (``halo_steps_bound``: 19 for r D = 0.3, H = 64; conservative bound
+# 1e-20 relative) before it has to be refreshed from the neighbours.  Between refreshes a rank runs the ORDINARY
+# single-GPU kernels on its extended block - S steps in one library call, 32 B per cell-update, no interface traffic -
+# and a refresh is one bulk exchange of H-wide strips (x first, then y across the already refreshed x-halos, which
+# fills the corners without diagonal messages).  Compared with the exact interface exchange above (``block_adi_steps``:
+# two latency-bound messages per step on the critical path) this trades ~2 H / n extra cells for 2 S times fewer, larger
+# messages; it is the mode the strong-scaling benchmark uses, the exact scheme remains for stiff steps (S < 1).
+HALO = 64
+
+
+def halo_steps_bound(a: float, halo: int = HALO, limit: float = 1e-20, cap: int = 64) -> int:
+    """Largest number of consecutive ADI steps for which a cut at distance ``halo`` perturbs the cells beyond it by less
+    than ``limit`` (relative to the field maximum), from a worst-case recursion in absolute values: per step the error is
+    mapped by |2 G - I| (G = inverse of the 1-D operator I - a L) in the cut direction, amplified by the absolute row sum
+    of the same operator for the sweep in the other direction, and a new cut error 2 a |G[:, cut]| (2 |u|max) is
+    injected; factor 4 for the two cut directions and the corners.  0 means: do not use the overlapped scheme."""
+    a = float(a)
+    if not a > 0.0:
+        return cap
+    n = halo + 3 * TILE
+    root = (1.0 + 4.0 * a) ** 0.5
+    rho = (1.0 + 2.0 * a - root) / (2.0 * a)          # decay of the Green's function of I - a L on the line
+    ginf = 1.0 / root                                  # its diagonal
+    idx = np.arange(n)
+    K = 4.0 * ginf * rho ** np.abs(idx[:, None] - idx[None, :])      # 2 G, doubled again for the images at the walls
+    K[idx, idx] = max(abs(2.0 * ginf - 1.0), abs(2.0 / (1.0 + a) - 1.0))
+    cross = max(1.0, 2.0 * ginf * (1.0 + rho) / (1.0 - rho) - 2.0 * ginf + abs(2.0 * ginf - 1.0))
+    inject = 2.0 * (2.0 * ginf) * rho ** idx * (2.0 * a)
+    E = np.zeros(n)
+    steps = 0
+    for s in range(1, cap + 1):
+        E = cross * (K @ E + inject)
+        if 4.0 * E[halo:].max() >= limit:
+            break
+        steps = s
+    return steps
+
+
+class OverlapBlock:
+    """One rank's block of a decomposed full-rectangle grid, extended by ``halo`` cells towards every neighbour.
+
+    ``u`` is a torch tensor [nfield, ey, ex] (device of the backend).  Subclasses implement ``advance(n)`` - n ADI steps
+    on the extended block with the physical boundary condition on physical sides and a reflective wall at the outer edge
+    of a halo.  Everything about strips, messages and the exchange cadence lives here, so the CPU test backend and the HIP
+    backend run the same orchestration."""
+
+    def __init__(self, topo: BlockTopology, nfield: int, a_max: float, halo: int = HALO, steps_per_exchange=None):
+        self.topo, self.nfield, self.halo = topo, int(nfield), int(halo)
+        j0, i0, ny, nx = topo.block
+        has = lambda d, s: topo.neighbour(d, s) is not None  # noqa: E731
+        self.hl, self.hr = (halo if has(0, 0) else 0), (halo if has(0, 1) else 0)
+        self.hu, self.hd = (halo if has(1, 0) else 0), (halo if has(1, 1) else 0)
+        if (self.hl or self.hr) and nx < halo or (self.hu or self.hd) and ny < halo:
+            raise ValueError(f"blocks of {ny} x {nx} cells are smaller than the halo ({halo})")
+        self.ny, self.nx = ny, nx
+        self.ey, self.ex = ny + self.hu + self.hd, nx + self.hl + self.hr
+        bound = halo_steps_bound(a_max, halo)
+        self.steps_per_exchange = bound if steps_per_exchange is None else min(int(steps_per_exchange), bound)
+        if self.steps_per_exchange < 1 and topo.py * topo.px > 1:
+            raise ValueError(f"r D = {a_max:.3g} is too stiff for the overlapped-halo scheme with a halo of {halo} cells; "
+                             "use the exact interface exchange (block_adi_steps)")
+        self.since_exchange = 0
+        self.u = None        # set by the subclass
+
+    # -- the block inside the extended array ----------------------------------------------------------------------
+    @property
+    def own(self):
+        return self.u[:, self.hu:self.hu + self.ny, self.hl:self.hl + self.nx]
+
+    def ext_origin(self) -> tuple[int, int]:
+        j0, i0, _, _ = self.topo.block
+        return j0 - self.hu, i0 - self.hl
+
+    def side_bcs(self, bc_diag, bc_src):
+        """(bc_diag[4], bc_src[4]) of the extended block: the physical condition on physical sides, reflective walls at the
+        outer edge of a halo (left, right, up, down)."""
+        cut = [self.hl > 0, self.hr > 0, self.hu > 0, self.hd > 0]
+        return ([0.0 if c else float(v) for c, v in zip(cut, bc_diag)],
+                [0.0 if c else float(v) for c, v in zip(cut, bc_src)])
+
+    # -- strips ----------------------------------------------------------------------------------------------------
+    def _send_strip(self, direction: int, side: int):
+        H = self.halo
+        if direction == 0:       # my first / last H own columns, own rows only
+            c0 = self.hl if side == 0 else self.hl + self.nx - H
+            return self.u[:, self.hu:self.hu + self.ny, c0:c0 + H]
+        r0 = self.hu if side == 0 else self.hu + self.ny - H
+        return self.u[:, r0:r0 + H, :]            # full extended width: carries the x-halos into the corners
+
+    def _recv_strip(self, direction: int, side: int):
+        if direction == 0:
+            c0 = 0 if side == 0 else self.hl + self.nx
+            return self.u[:, self.hu:self.hu + self.ny, c0:c0 + self.halo]
+        r0 = 0 if side == 0 else self.hu + self.ny
+        return self.u[:, r0:r0 + self.halo, :]
+
+    def exchange_messages(self, direction: int):
+        """(sends, recvs, unpack) of the halo refresh along ``direction`` (0: left/right strips, 1: up/down strips)."""
+        sends, recvs, after = {}, {}, []
+        for side in (0, 1):
+            peer = self.topo.neighbour(direction, side)
+            if peer is None:
+                continue
+            sends[peer] = self._send_strip(direction, side).contiguous()
+            dst = self._recv_strip(direction, side)
+            buf = dst.new_empty(dst.shape)
+            recvs[peer] = buf
+            after.append(lambda d=dst, b=buf: d.copy_(b))
+        return sends, recvs, after
+
+    def advance(self, nsteps: int) -> None:
+        raise NotImplementedError
+
+
+def overlap_stages(nsteps: int, steps_per_exchange: int, since_exchange: int):
+    """("steps", n) and ("exchange", direction) stages of ``nsteps`` steps; returns through StopIteration nothing - the caller
+    tracks ``since_exchange`` with the same arithmetic (``overlap_advance_counter``)."""
+    left, since = int(nsteps), int(since_exchange)
+    while left > 0:
+        if since >= steps_per_exchange:
+            yield ("exchange", 0)
+            yield ("exchange", 1)
+            since = 0
+        n = min(left, steps_per_exchange - since)
+        yield ("steps", n)
+        left -= n
+        since += n
+
+
+def overlap_adi_steps(block: OverlapBlock, transport, nsteps: int, exchange: bool = True) -> None:
+    """Advance the local block by ``nsteps`` ADI steps; every rank calls this collectively with the same ``nsteps``.
+    ``exchange=False`` skips the halo refreshes (timing of the exchange share only - results are then wrong)."""
+    single = block.topo.py * block.topo.px == 1
+    spe = max(block.steps_per_exchange, 1) if not single else max(int(nsteps), 1)
+    for kind, arg in overlap_stages(nsteps, spe, block.since_exchange):
+        if kind == "steps":
+            block.advance(arg)
+            block.since_exchange += arg
+        elif arg == 0:
+            block.since_exchange = 0
+            if exchange and not single:
+                sends, recvs, after = block.exchange_messages(0)
+                transport.exchange(sends, recvs)
+                for fn in after:
+                    fn()
+        elif exchange and not single:
+            sends, recvs, after = block.exchange_messages(1)
+            transport.exchange(sends, recvs)
+            for fn in after:
+                fn()
+
+
+def lockstep_overlap_steps(blocks: list, nsteps: int) -> None:
+    """The same sequence for several virtual ranks living in this process."""
+    mail = LocalTransport()
+    spe = blocks[0].steps_per_exchange
+    for kind, arg in overlap_stages(nsteps, spe, blocks[0].since_exchange):
+        if kind == "steps":
+            for b in blocks:
+                b.advance(arg)
+                b.since_exchange += arg
+            continue
+        pending = []
+        for b in blocks:
+            if arg == 0:
+                b.since_exchange = 0
+            sends, recvs, after = b.exchange_messages(arg)
+            mail.post(b.topo.rank, sends)
+            pending.append((b.topo.rank, recvs, after))
+        for rank, recvs, after in pending:
+            mail.collect(rank, recvs)
+            for fn in after:
+                fn()
+
+
+class HipOverlapBlock(OverlapBlock):
+    """Overlapped-halo block on one GPU: an ordinary (undecomposed) ``qp_adi_rect_plan`` on the extended block."""
+
+    def __init__(self, topo: BlockTopology, dx: float, dt: float, dcoef, bc_diag, bc_src, halo: int = HALO, device=None,
+                 steps_per_exchange=None):
+        from . import _hip
+        from .engine import RectPlan, require_gpu
+        torch = require_gpu()
+        r = 0.5 * dt / (dx * dx)
+        super().__init__(topo, len(dcoef), r * float(max(dcoef)), halo, steps_per_exchange)
+        self.torch, self.lib, self._hip = torch, _hip.load(), _hip
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        bd, bs = self.side_bcs(bc_diag, bc_src)
+        with torch.cuda.device(self.device):
+            self.plan = RectPlan(self.lib, self.ey, self.ex, self.nfield, r, dcoef, bd, bs)
+        self.u = torch.zeros(self.nfield, self.ey, self.ex, dtype=torch.float64, device=self.device)
+
+    def set_field(self, global_planes: np.ndarray) -> None:
+        """global_planes [nfield, gny, gnx] (host) -> extended local block (own cells and halos)."""
+        j0, i0 = self.ext_origin()
+        loc = np.ascontiguousarray(global_planes[:, j0:j0 + self.ey, i0:i0 + self.ex])
+        self.u.copy_(self.torch.as_tensor(loc, device=self.device))
+        self.since_exchange = 0
+
+    def get_field(self) -> np.ndarray:
+        return self.own.cpu().numpy()
+
+    def advance(self, nsteps: int) -> None:
+        stream = int(self.torch.cuda.current_stream(self.device).cuda_stream)
+        self._hip.check(self.lib.qp_adi_rect_steps(self.plan.handle, int(self.u.data_ptr()), int(nsteps), stream),
+                        "qp_adi_rect_steps")

@@ -147,3 +147,44 @@ class NumpyBlockBackend:
             pass
         else:
             raise ValueError(ph)
+
+
+class NumpyOverlapBlock:
+    """CPU twin of ``qpsim_amd.distributed.HipOverlapBlock``: the oracle's ADI stepper on the extended block (physical
+    boundary condition on physical sides, reflective wall at the outer edge of a halo)."""
+
+    def __new__(cls, topo, dx, dt, dcoef, side_bc, halo=64, steps_per_exchange=None):
+        from oracle import qp_oracle as O
+        from qpsim_amd.distributed import OverlapBlock
+        from qpsim_amd.geometry import extract_edge_segments
+        from qpsim_amd.models import BoundaryCondition
+
+        class _Impl(OverlapBlock):
+            def __init__(self):
+                r = 0.5 * dt / (dx * dx)
+                super().__init__(topo, len(dcoef), r * max(dcoef), halo, steps_per_exchange)
+                mask = np.ones((self.ey, self.ex), dtype=bool)
+                edges = extract_edge_segments(mask)
+                cut = {"left": self.hl > 0, "right": self.hr > 0, "up": self.hu > 0, "down": self.hd > 0}
+                bcs = {e.edge_id: (BoundaryCondition("reflective") if cut[e.normal] else side_bc[e.normal]) for e in edges}
+                ops = O.build_grid_ops(mask, edges, bcs, dx)
+                self.steppers = [O.ADIStepper(ops, d, dt) for d in dcoef]
+                self.u = torch.zeros(self.nfield, self.ey, self.ex, dtype=torch.float64)
+
+            def set_field(self, global_planes):
+                j0, i0 = self.ext_origin()
+                self.u.copy_(torch.from_numpy(np.ascontiguousarray(global_planes[:, j0:j0 + self.ey, i0:i0 + self.ex])))
+                self.since_exchange = 0
+
+            def get_field(self):
+                return self.own.numpy().copy()
+
+            def advance(self, nsteps):
+                a = self.u.numpy()
+                for k, st in enumerate(self.steppers):
+                    g = a[k].copy()
+                    for _ in range(nsteps):
+                        g = st.step_grid(g)
+                    a[k] = g
+
+        return _Impl()

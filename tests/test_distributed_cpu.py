@@ -13,10 +13,11 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from dd_reference import NumpyBlockBackend
+from dd_reference import NumpyBlockBackend, NumpyOverlapBlock
 from oracle import qp_oracle as O
 from qpsim_amd.distributed import (BlockTopology, TorchDistTransport, block_adi_steps, choose_process_grid,
-                                   lockstep_adi_steps, shard_members, split_extent)
+                                   halo_steps_bound, lockstep_adi_steps, lockstep_overlap_steps, overlap_adi_steps,
+                                   overlap_stages, shard_members, split_extent)
 from qpsim_amd.geometry import extract_edge_segments
 from qpsim_amd.models import BoundaryCondition
 
@@ -80,6 +81,65 @@ def test_decomposed_step_sequence_with_virtual_ranks_matches_global_adi(py, px, 
         assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 1e-12
 
 
+SIDE_BC = {"left": BoundaryCondition("dirichlet", 0.7), "right": BoundaryCondition("robin", 0.4, 0.2),
+           "up": BoundaryCondition("neumann", -0.3), "down": BoundaryCondition("absorbing")}
+
+
+def test_halo_step_bound_and_stage_sequence():
+    # benchmark configuration r D = 0.3: ~19 steps per refresh with a one-tile halo; stiffer steps get fewer, very stiff none
+    assert 12 <= halo_steps_bound(0.3) <= 24 and halo_steps_bound(0.3, halo=128) > 40
+    assert halo_steps_bound(0.1) > halo_steps_bound(0.3) > halo_steps_bound(0.75) > halo_steps_bound(1.5) >= 1
+    assert halo_steps_bound(5.0) == 0
+    seq = list(overlap_stages(10, 4, 0))
+    assert seq == [("steps", 4), ("exchange", 0), ("exchange", 1), ("steps", 4), ("exchange", 0), ("exchange", 1), ("steps", 2)]
+    assert list(overlap_stages(3, 4, 2)) == [("steps", 2), ("exchange", 0), ("exchange", 1), ("steps", 1)]
+    assert list(overlap_stages(2, 4, 4)) == [("exchange", 0), ("exchange", 1), ("steps", 2)]
+
+
+@pytest.mark.parametrize("py,px,gny,gnx", [(1, 2, 70, 192), (2, 1, 192, 70), (2, 2, 192, 200), (1, 3, 64, 256)])
+def test_overlapped_halo_blocks_with_virtual_ranks_match_global_adi(py, px, gny, gnx):
+    """Each virtual rank runs the plain ADI steps on its block + 64-cell halos and the halos are refreshed every 3 steps:
+    the own cells must equal the global ADI solution to rounding (the cut error is ~rho^64)."""
+    mask, edges, bcs, dx, dt, D, bc_diag, bc_src, u0 = _problem(gny, gnx)
+    topos = [BlockTopology(gny, gnx, py, px, r) for r in range(py * px)]
+    blocks = [NumpyOverlapBlock(t, dx, dt, D, SIDE_BC, steps_per_exchange=3) for t in topos]
+    for b in blocks:
+        b.set_field(u0)
+    total = 0
+    for nsteps in (2, 5):            # 7 steps in two calls: refreshes after steps 3 and 6, one of them inside a call
+        lockstep_overlap_steps(blocks, nsteps)
+        total += nsteps
+        got = np.zeros_like(u0)
+        for b, t in zip(blocks, topos):
+            j0, i0, ny, nx = t.block
+            got[:, j0:j0 + ny, i0:i0 + nx] = b.get_field()
+        want = _oracle_steps(mask, edges, bcs, dx, dt, D, u0, total)
+        assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 1e-13, (nsteps, total)
+    assert blocks[0].since_exchange == 1
+
+
+def test_overlapped_halo_without_refresh_drifts_at_diffusion_speed():
+    """Control: with the refresh skipped the cut at the outer halo edge reaches the own cells at the speed of diffusion
+    (exp(-64^2 / (8 a N)) after N steps) - invisible after 40 steps, plain after 250; with refreshes it never does."""
+    gny, gnx = 64, 192
+    mask, edges, bcs, dx, dt, D, bc_diag, bc_src, u0 = _problem(gny, gnx)
+    topos = [BlockTopology(gny, gnx, 1, 2, r) for r in range(2)]
+    errs = {}
+    for refresh in (False, True):
+        blocks = [NumpyOverlapBlock(t, dx, dt, D, SIDE_BC, steps_per_exchange=10) for t in topos]
+        for b in blocks:
+            b.set_field(u0)
+        if refresh:
+            lockstep_overlap_steps(blocks, 250)
+        else:
+            for b in blocks:
+                overlap_adi_steps(b, None, 250, exchange=False)
+        got = np.concatenate([b.get_field() for b in blocks], axis=2)
+        want = _oracle_steps(mask, edges, bcs, dx, dt, D, u0, 250)
+        errs[refresh] = np.max(np.abs(got - want)) / np.max(np.abs(want))
+    assert errs[True] < 1e-13 and errs[False] > 1e-7, errs
+
+
 def _free_port() -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -100,6 +160,11 @@ def _gloo_worker(rank, world, port, py, px, gny, gnx, nsteps, out_dir):
         be.set_field(u0)
         block_adi_steps(be, topo, TorchDistTransport(), nsteps)
         np.save(os.path.join(out_dir, f"block_{rank}.npy"), be.get_field())
+        # the overlapped-halo scheme over the same transport: 5 steps, halos refreshed every 2
+        ob = NumpyOverlapBlock(topo, dx, dt, D, SIDE_BC, steps_per_exchange=2)
+        ob.set_field(u0)
+        overlap_adi_steps(ob, TorchDistTransport(), 5)
+        np.save(os.path.join(out_dir, f"overlap_{rank}.npy"), ob.get_field())
         # ensemble mode: independent members, no communication; only a final gather of scalars
         mine = shard_members(7, world, rank)
         total = torch.tensor([float(sum(mine))], dtype=torch.float64)
@@ -121,3 +186,8 @@ def test_decomposed_steps_over_gloo_world_size_2(tmp_path, py, px):
         got[:, j0:j0 + ny, i0:i0 + nx] = np.load(tmp_path / f"block_{r}.npy")
     want = _oracle_steps(mask, edges, bcs, dx, dt, D, u0, nsteps)
     assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 1e-12
+    for r in range(2):
+        j0, i0, ny, nx = BlockTopology(gny, gnx, py, px, r).block
+        got[:, j0:j0 + ny, i0:i0 + nx] = np.load(tmp_path / f"overlap_{r}.npy")
+    want = _oracle_steps(mask, edges, bcs, dx, dt, D, u0, 5)
+    assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 1e-13

@@ -85,3 +85,72 @@ def test_two_processes_share_the_gpu_and_exchange_over_gloo(tmp_path):
         got[:, j0:j0 + ny, i0:i0 + nx] = np.load(tmp_path / f"block_{r}.npy")
     want = _oracle(mask, edges, bcs, dx, dt, D, u0, nsteps)
     assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 2e-13
+
+
+@pytest.mark.parametrize("py,px,gny,gnx", [(1, 2, 64, 192), (2, 1, 192, 70), (2, 2, 192, 256), (2, 4, 256, 512)])
+def test_hip_overlapped_halo_blocks_match_global_adi(py, px, gny, gnx):
+    """Overlapped-halo decomposition on the GPU (virtual ranks in lock-step): ordinary single-GPU plans on block + 64-cell
+    halos, halos refreshed every 3 steps, 8 steps in two calls - own cells equal the global ADI solution to rounding."""
+    from qpsim_amd.distributed import BlockTopology, HipOverlapBlock, lockstep_overlap_steps
+    mask, edges, bcs, dx, dt, D, bc_diag, bc_src, u0 = _setup(gny, gnx)
+    topos = [BlockTopology(gny, gnx, py, px, r) for r in range(py * px)]
+    blocks = [HipOverlapBlock(t, dx, dt, D, bc_diag, bc_src, steps_per_exchange=3) for t in topos]
+    assert all(b.steps_per_exchange == 3 for b in blocks)
+    for b in blocks:
+        b.set_field(u0)
+    total = 0
+    for nsteps in (2, 6):
+        lockstep_overlap_steps(blocks, nsteps)
+        total += nsteps
+        got = np.zeros_like(u0)
+        for b, t in zip(blocks, topos):
+            j0, i0, ny, nx = t.block
+            got[:, j0:j0 + ny, i0:i0 + nx] = b.get_field()
+        want = _oracle(mask, edges, bcs, dx, dt, D, u0, total)
+        assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 2e-13, total
+
+
+def test_overlapped_halo_scheme_refuses_stiff_steps():
+    from qpsim_amd.distributed import BlockTopology, HipOverlapBlock
+    mask, edges, bcs, dx, dt, D, bc_diag, bc_src, u0 = _setup(128, 128)
+    with pytest.raises(ValueError, match="too stiff"):
+        HipOverlapBlock(BlockTopology(128, 128, 1, 2, 0), dx, dt, [400.0], bc_diag, bc_src)
+    with pytest.raises(ValueError, match="smaller than the halo"):
+        HipOverlapBlock(BlockTopology(96, 128, 2, 1, 1), dx, dt, [6.0], bc_diag, bc_src)
+
+
+def _overlap_worker(rank, world, port, py, px, gny, gnx, nsteps, out_dir):
+    for p in (str(ROOT), str(ROOT / "quasiparticle-physics-simulation_amd"), str(ROOT / "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from qpsim_amd.distributed import BlockTopology, HipOverlapBlock, TorchDistTransport, overlap_adi_steps
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mask, edges, bcs, dx, dt, D, bc_diag, bc_src, u0 = _setup(gny, gnx)
+        topo = BlockTopology(gny, gnx, py, px, rank)
+        blk = HipOverlapBlock(topo, dx, dt, D, bc_diag, bc_src, device="cuda:0", steps_per_exchange=2)
+        blk.set_field(u0)
+        overlap_adi_steps(blk, TorchDistTransport(), nsteps)
+        np.save(os.path.join(out_dir, f"block_{rank}.npy"), blk.get_field())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_refresh_halos_over_gloo(tmp_path):
+    """Two real processes on the one GPU, gloo as the transport (device strips staged through the host): the call sequence
+    every rank of the RCCL run executes."""
+    import torch.multiprocessing as mp
+    from qpsim_amd.distributed import BlockTopology
+    from test_distributed_cpu import _free_port
+    py, px, gny, gnx, nsteps = 2, 1, 192, 160, 5
+    mp.spawn(_overlap_worker, args=(2, _free_port(), py, px, gny, gnx, nsteps, str(tmp_path)), nprocs=2, join=True)
+    mask, edges, bcs, dx, dt, D, bc_diag, bc_src, u0 = _setup(gny, gnx)
+    got = np.zeros_like(u0)
+    for r in range(2):
+        j0, i0, ny, nx = BlockTopology(gny, gnx, py, px, r).block
+        got[:, j0:j0 + ny, i0:i0 + nx] = np.load(tmp_path / f"block_{r}.npy")
+    want = _oracle(mask, edges, bcs, dx, dt, D, u0, nsteps)
+    assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 2e-13
