@@ -57,6 +57,8 @@ def parse_args():
     ap.add_argument("--cpu-size", type=int, default=512, help="grid edge of the bounded CPU-baseline sample")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with one rank")
     ap.add_argument("--no-subrecords", action="store_true", help="N > 1: skip the strong-scaling / ensemble sub-records")
+    ap.add_argument("--force-subrecords", action="store_true",
+                    help="emit the sub-records with one rank too (with --force-dist: rehearsal of the N > 1 code path)")
     ap.add_argument("--strong-size", type=int, default=8192, help="grid edge of the strong-scaling sub-record")
     return ap.parse_args()
 
@@ -263,7 +265,7 @@ def main():
         result["pixel_steps_per_s"] = wl.npix * world * args.steps / elapsed
     del wl
     torch.cuda.empty_cache()
-    if world > 1 and not args.no_subrecords and args.workload == "adi4096":
+    if (world > 1 or (args.force_subrecords and use_dist)) and not args.no_subrecords and args.workload == "adi4096":
         # north_star's two multi-GPU figures, measured in the same run and reported next to the weak-scaling headline
         result["strong"] = strong_scaling_record(args, dev, world, rank)
         result["ensemble"] = ensemble_record(args, dev, world)

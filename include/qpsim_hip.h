@@ -152,6 +152,19 @@ int qp_collision_step(const qp_collision_tables* t, const uint8_t* flags, int64_
                       double* state_out, double* phonon, double* ph_scratch, double dE, double dt,
                       int enable_recombination, int enable_scattering, int update_phonons, void* stream);
 
+/*
+ * qp_collision_step followed by qp_pauli_stats on state_out (the guard of solver.py:1477 after the last collision of a step),
+ * as ONE call: the single-pass register kernels (ne < 32) reduce the occupation statistics of the new densities while they
+ * are still in registers - one partial per wave into guard_workspace, finished by two small launches - which saves the
+ * separate pass over the ne planes (7 % of a 4096^2, ne = 12 coupled step).  Other kernels run the separate pass.
+ * out_vals / out_idx as qp_pauli_stats (bit-identical results); guard_workspace: qp_collision_guard_workspace_bytes(ncell).
+ */
+int64_t qp_collision_guard_workspace_bytes(int64_t ncell);
+int qp_collision_step_guarded(const qp_collision_tables* t, const uint8_t* flags, int64_t ncell, const double* state_in,
+                              double* state_out, double* phonon, double* ph_scratch, double dE, double dt,
+                              int enable_recombination, int enable_scattering, int update_phonons, double density_floor,
+                              void* guard_workspace, double* out_vals, int64_t* out_idx, void* stream);
+
 /* 1 when qp_collision_step has a register-resident kernel for `ne` energy bins (structured, unshared bin maps and one gap
  * class are the other conditions); other sizes <= 64 run the one-wave-per-pixel kernel, larger ones the generic kernel. */
 int qp_collision_register_kernel_available(int32_t ne);

@@ -575,6 +575,10 @@ struct qp_adi_tile_plan {
   int counts[3] = {0, 0, 0};       // empty, clean, general tiles
   size_t bct_bytes = 0;
   double far = 0.0;
+  // Tuning knob QPSIM_TILE_FORK=1: the general tiles (a ring in 4096^2: 328 single-wave blocks for 1024 SIMDs, launched after
+  // the clean tiles) go to a side stream, forked from and joined to the caller's stream with events around every sweep.
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 extern "C" {
@@ -582,6 +586,9 @@ extern "C" {
 int qp_adi_tile_plan_destroy(qp_adi_tile_plan* plan) {
   if (!plan) return QP_OK;
   for (void* p : plan->allocs) (void)hipFree(p);
+  if (plan->side) (void)hipStreamDestroy(plan->side);
+  if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
+  if (plan->ev_join) (void)hipEventDestroy(plan->ev_join);
   delete plan;
   return QP_OK;
 }
@@ -762,6 +769,20 @@ static int tile_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, co
               far, kFarCouplingDrop);
     return QP_ERR_UNSUPPORTED;
   }
+  {
+    // opt-in (QPSIM_TILE_FORK=1): measured on MI355X the event fork / join costs more than the overlap gains for one field
+    // (ring in 4096^2: 0.113 -> 0.131 ms per step) and gains 4 % for four fields
+    const char* e = getenv("QPSIM_TILE_FORK");
+    if (v.ntiles[0] > 0 && v.ntiles[1] > 0 && !var && e && atoi(e) != 0) {
+      if (hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&plan->ev_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        if (plan->side) (void)hipStreamDestroy(plan->side);
+        plan->side = nullptr;      // no side stream: the launches stay in order on the caller's stream
+      }
+    }
+  }
   *out = plan;
   return QP_OK;
 }
@@ -791,9 +812,23 @@ int qp_adi_tile_plan_info(const qp_adi_tile_plan* plan, int32_t* counts, double*
 
 namespace qp {
 
+// general tiles on the side stream: fork before the sweep's launches, join after them
+static hipStream_t fork_general(const qp_adi_tile_plan* plan, hipStream_t stream) {
+  if (!plan->side) return stream;
+  (void)hipEventRecord(plan->ev_fork, stream);
+  (void)hipStreamWaitEvent(plan->side, plan->ev_fork, 0);
+  return plan->side;
+}
+static void join_general(const qp_adi_tile_plan* plan, hipStream_t stream) {
+  if (!plan->side) return;
+  (void)hipEventRecord(plan->ev_join, plan->side);
+  (void)hipStreamWaitEvent(stream, plan->ev_join, 0);
+}
+
 template <bool EXPLICIT>
 static void launch_x(const qp_adi_tile_plan* plan, double* buf, hipStream_t stream) {
   const TileView& v = plan->view;
+  const hipStream_t gstream = fork_general(plan, stream);
   if (v.ntiles[0] > 0) {
     const dim3 grid((unsigned)((long)v.ntiles[0] * v.nfield));
     if (v.compact) {
@@ -808,15 +843,17 @@ static void launch_x(const qp_adi_tile_plan* plan, double* buf, hipStream_t stre
   }
   if (v.ntiles[1] > 0 && !v.var)
     hipLaunchKernelGGL((tile_x_kernel<1, EXPLICIT, -1>), dim3((unsigned)((long)v.ntiles[1] * v.nfield)), dim3(64),
-                       plan->bct_bytes, stream, v, buf);
+                       plan->bct_bytes, gstream, v, buf);
   if (v.ntiles[1] > 0 && v.var)
     hipLaunchKernelGGL((tile_x_kernel<2, EXPLICIT, -1>), dim3((unsigned)((long)v.ntiles[1] * v.nfield)), dim3(64),
                        plan->bct_bytes, stream, v, buf);
+  join_general(plan, stream);
 }
 
 template <int MODE>
 static void launch_y(const qp_adi_tile_plan* plan, const double* src, double* dst, hipStream_t stream) {
   const TileView& v = plan->view;
+  const hipStream_t gstream = fork_general(plan, stream);
   if (v.ntiles[0] > 0) {
     const dim3 grid((unsigned)((long)v.ntiles[0] * v.nfield));
     if (v.compact) {
@@ -831,10 +868,11 @@ static void launch_y(const qp_adi_tile_plan* plan, const double* src, double* ds
   }
   if (v.ntiles[1] > 0 && !v.var)
     hipLaunchKernelGGL((tile_y_kernel<1, MODE, -1>), dim3((unsigned)((long)v.ntiles[1] * v.nfield)), dim3(64),
-                       plan->bct_bytes, stream, v, src, dst);
+                       plan->bct_bytes, gstream, v, src, dst);
   if (v.ntiles[1] > 0 && v.var)
     hipLaunchKernelGGL((tile_y_kernel<2, MODE, -1>), dim3((unsigned)((long)v.ntiles[1] * v.nfield)), dim3(64),
                        plan->bct_bytes, stream, v, src, dst);
+  join_general(plan, stream);
 }
 
 }  // namespace qp

@@ -131,14 +131,15 @@ __global__ void __launch_bounds__(256) collision_generic_kernel(CollView t, cons
 bool collision_fast_dispatch(int ne, const double* kr0, const double* ks0, const double* rho, const int* diag_bin,
                              const int* anti_bin, double* stash, const uint8_t* flags, long ncell, const double* sin_,
                              double* sout, double* ph, double dE, double dt, int en_r, int en_s, int upd,
-                             hipStream_t stream);
+                             PauliPartial* guard, double guard_floor, bool* guard_done, hipStream_t stream);
 
 int collision_fast_supported(int ne);
 int collision_fast_classes_supported(int ne);
 bool collision_fast_dispatch_classes(int ne, const double* rho, const int* cls, const double* gap_sq, const double* kr_amp,
                                      const double* ks_amp, const double* pair_inv, const int* diag_bin, const int* anti_bin,
                                      double* stash, const uint8_t* flags, long ncell, const double* sin_, double* sout,
-                                     double* ph, double dE, double dt, int en_r, int en_s, int upd, hipStream_t stream);
+                                     double* ph, double dE, double dt, int en_r, int en_s, int upd, PauliPartial* guard,
+                                     double guard_floor, bool* guard_done, hipStream_t stream);
 
 struct WaveCollView {
   int ne, nw, nclass;
@@ -158,10 +159,12 @@ bool collision_wave_dispatch(const WaveCollView& v, bool structured, const uint8
 
 }  // namespace qp
 
-extern "C" int qp_collision_step(const qp_collision_tables* t, const uint8_t* flags, int64_t ncell,
-                                 const double* state_in, double* state_out, double* phonon, double* ph_scratch,
-                                 double dE, double dt, int enable_recombination, int enable_scattering,
-                                 int update_phonons, void* stream) {
+static int collision_step_impl(const qp_collision_tables* t, const uint8_t* flags, int64_t ncell,
+                               const double* state_in, double* state_out, double* phonon, double* ph_scratch,
+                               double dE, double dt, int enable_recombination, int enable_scattering,
+                               int update_phonons, qp::PauliPartial* guard, double guard_floor, bool* guard_done,
+                               void* stream) {
+  if (guard_done) *guard_done = false;
   QP_REQUIRE(t != nullptr, "tables are NULL");
   if (t->struct_size != sizeof(qp_collision_tables)) {
     qp::set_error("qp_collision_step: qp_collision_tables.struct_size is %u, this library expects %zu (binding built against "
@@ -185,7 +188,7 @@ extern "C" int qp_collision_step(const qp_collision_tables* t, const uint8_t* fl
   if (t->diag_bin && t->nclass == 1 && !(t->flags & (QP_COLL_FORCE_GENERIC | QP_COLL_FORCE_WAVE)) && shared_ok &&
       qp::collision_fast_dispatch(t->ne, t->kr0, t->ks0, t->rho, t->diag_bin, t->anti_bin, ph_scratch, flags, (long)ncell,
                                   state_in, state_out, phonon, dE, dt, enable_recombination, enable_scattering,
-                                  update_phonons, (hipStream_t)stream))
+                                  update_phonons, guard, guard_floor, guard_done, (hipStream_t)stream))
     return qp::check_launch("qp_collision_step(fast)");
   // gap classes with the separable kernel tables: register kernel that forms K per pixel
   if (t->diag_bin && t->nclass > 1 && t->gap_sq && t->pair_inv && t->cls &&
@@ -194,7 +197,8 @@ extern "C" int qp_collision_step(const qp_collision_tables* t, const uint8_t* fl
       qp::collision_fast_dispatch_classes(t->ne, t->rho, t->cls, t->gap_sq, enable_recombination ? t->kr_amp : nullptr,
                                           enable_scattering ? t->ks_amp : nullptr, t->pair_inv, t->diag_bin, t->anti_bin,
                                           ph_scratch, flags, (long)ncell, state_in, state_out, phonon, dE, dt,
-                                          enable_recombination, enable_scattering, update_phonons, (hipStream_t)stream))
+                                          enable_recombination, enable_scattering, update_phonons, guard, guard_floor,
+                                          guard_done, (hipStream_t)stream))
     return qp::check_launch("qp_collision_step(fast, gap classes)");
   // NE <= 64: one wave per pixel (any class map; LDS atomics unless the host vouched for the bin-map structure)
   if (!(t->flags & QP_COLL_FORCE_GENERIC)) {
@@ -210,6 +214,43 @@ extern "C" int qp_collision_step(const qp_collision_tables* t, const uint8_t* fl
                      (long)ncell, state_in, state_out, phonon, ph_scratch, dE, dt, enable_recombination,
                      enable_scattering, update_phonons);
   return qp::check_launch("qp_collision_step");
+}
+
+extern "C" int qp_collision_step(const qp_collision_tables* t, const uint8_t* flags, int64_t ncell,
+                                 const double* state_in, double* state_out, double* phonon, double* ph_scratch,
+                                 double dE, double dt, int enable_recombination, int enable_scattering,
+                                 int update_phonons, void* stream) {
+  return collision_step_impl(t, flags, ncell, state_in, state_out, phonon, ph_scratch, dE, dt, enable_recombination,
+                             enable_scattering, update_phonons, nullptr, 0.0, nullptr, stream);
+}
+
+extern "C" int64_t qp_collision_guard_workspace_bytes(int64_t ncell) {
+  const int64_t waves = (ncell + 63) / 64 + qp::kGuardMergeBlocks;
+  const int64_t fused = waves * (int64_t)sizeof(qp::PauliPartial);
+  const int64_t plain = qp_pauli_workspace_bytes();
+  return fused > plain ? fused : plain;
+}
+
+extern "C" int qp_collision_step_guarded(const qp_collision_tables* t, const uint8_t* flags, int64_t ncell,
+                                         const double* state_in, double* state_out, double* phonon, double* ph_scratch,
+                                         double dE, double dt, int enable_recombination, int enable_scattering,
+                                         int update_phonons, double density_floor, void* guard_workspace,
+                                         double* out_vals, int64_t* out_idx, void* stream) {
+  QP_REQUIRE(guard_workspace && out_vals && out_idx, "guard_workspace, out_vals, out_idx must be non-NULL");
+  auto* parts = (qp::PauliPartial*)guard_workspace;
+  bool done = false;
+  const int rc = collision_step_impl(t, flags, ncell, state_in, state_out, phonon, ph_scratch, dE, dt, enable_recombination,
+                                     enable_scattering, update_phonons, parts + qp::kGuardMergeBlocks, density_floor, &done,
+                                     stream);
+  if (rc != QP_OK) return rc;
+  if (done) {      // one partial per wave of the register kernel (128-thread blocks): finish the reduction
+    const long nparts = ((long)ncell + 127) / 128 * 2;
+    qp::pauli_finish(parts + qp::kGuardMergeBlocks, nparts, parts, out_vals, (long*)out_idx, (hipStream_t)stream);
+    return qp::check_launch("qp_collision_step_guarded");
+  }
+  // kernels without the fused epilogue (split kernels of NE >= 32, wave and generic kernels): separate pass
+  return qp_pauli_stats(state_out, t->rho, t->cls, flags, t->ne, t->nclass, ncell, density_floor, guard_workspace,
+                        out_vals, out_idx, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -33,12 +33,16 @@ __global__ void __launch_bounds__(256) collision_none_kernel(const uint8_t* __re
 }
 
 // returns false when NE has no instantiation or the cell count exceeds the 32-bit offset range
+// `guard` (may be NULL): per-wave partials of the fused Pauli guard; *guard_done tells whether the kernels wrote them (the
+// single-pass sizes do, the split kernels of NE >= 32 and the no-process copy do not)
 bool collision_fast_dispatch(int ne, const double* kr0, const double* ks0, const double* rho, const int* diag_bin,
                              const int* anti_bin, double* stash, const uint8_t* flags, long ncell, const double* sin_,
                              double* sout, double* ph, double dE, double dt, int en_r, int en_s, int upd,
-                             hipStream_t stream) {
+                             PauliPartial* guard, double guard_floor, bool* guard_done, hipStream_t stream) {
+  if (guard_done) *guard_done = false;
   if (ncell >= (1L << 28)) return false;
-  CollFastView v{kr0, ks0, rho, diag_bin, anti_bin, stash, nullptr, nullptr, nullptr, nullptr, nullptr};
+  CollFastView v{kr0, ks0, rho, diag_bin, anti_bin, stash, nullptr, nullptr, nullptr, nullptr, nullptr,
+                 ne < 32 ? guard : nullptr, guard_floor};
   const bool s = en_s && ks0, r = en_r && kr0, u = upd && (s || r);
   diag_launcher_t fn = nullptr;
   switch (ne) {
@@ -54,6 +58,7 @@ bool collision_fast_dispatch(int ne, const double* kr0, const double* ks0, const
     return true;
   }
   fn(v, flags, ncell, sin_, sout, ph, dE, dt, u, stream);
+  if (guard_done) *guard_done = v.guard != nullptr;
   return true;
 }
 
@@ -62,9 +67,11 @@ bool collision_fast_dispatch(int ne, const double* kr0, const double* ks0, const
 bool collision_fast_dispatch_classes(int ne, const double* rho, const int* cls, const double* gap_sq, const double* kr_amp,
                                      const double* ks_amp, const double* pair_inv, const int* diag_bin, const int* anti_bin,
                                      double* stash, const uint8_t* flags, long ncell, const double* sin_, double* sout,
-                                     double* ph, double dE, double dt, int en_r, int en_s, int upd, hipStream_t stream) {
+                                     double* ph, double dE, double dt, int en_r, int en_s, int upd, PauliPartial* guard,
+                                     double guard_floor, bool* guard_done, hipStream_t stream) {
+  if (guard_done) *guard_done = false;
   if (ncell >= (1L << 28)) return false;
-  CollFastView v{nullptr, nullptr, rho, diag_bin, anti_bin, stash, cls, gap_sq, kr_amp, ks_amp, pair_inv};
+  CollFastView v{nullptr, nullptr, rho, diag_bin, anti_bin, stash, cls, gap_sq, kr_amp, ks_amp, pair_inv, guard, guard_floor};
   const bool s = en_s && ks_amp, r = en_r && kr_amp, u = upd && (s || r);
   if (!s && !r) return false;
   diag_launcher_t fn = nullptr;
@@ -76,6 +83,7 @@ bool collision_fast_dispatch_classes(int ne, const double* rho, const int* cls, 
     default: return false;
   }
   fn(v, flags, ncell, sin_, sout, ph, dE, dt, u, stream);
+  if (guard_done) *guard_done = guard != nullptr;
   return true;
 }
 

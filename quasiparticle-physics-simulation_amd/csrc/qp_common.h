@@ -51,6 +51,19 @@ inline GridView make_view(const qp_grid_desc* g) {
 
 int validate_grid(const qp_grid_desc* g, const char* who);
 
+// Partial result of the Pauli-guard reduction (qp_misc.hip): largest occupation with its linear index ie*ncell + p
+// (np.argmax order: first maximum in C order, a NaN counts as the maximum) and the first forbidden linear index or -1.
+struct PauliPartial {
+  double maxf;
+  long maxidx;
+  long forb;
+};
+constexpr int kGuardMergeBlocks = 64;
+// reduces `nparts` partials (written by the collision kernels, one per wave) to out_vals[0], out_idx[0..1];
+// `scratch` holds kGuardMergeBlocks partials
+void pauli_finish(const PauliPartial* parts, long nparts, PauliPartial* scratch, double* out_vals, long* out_idx,
+                  hipStream_t stream);
+
 // Harmonic-mean face diffusivity (solver.py:283).
 __device__ __forceinline__ double face_mean(double dp, double dq) {
   return 2.0 * dp * dq / fmax(dp + dq, 1e-30);

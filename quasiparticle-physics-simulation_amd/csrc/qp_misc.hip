@@ -52,12 +52,6 @@ __global__ void __launch_bounds__(256) weighted_sum_kernel(const double* __restr
 // ---- reductions: per-block partials in workspace, finished by a single-block kernel -----------------------
 constexpr int kRedBlocks = 1024;
 
-struct PauliPartial {
-  double maxf;
-  long maxidx;
-  long forb;
-};
-
 // np.argmax order (solver.py:993): a NaN occupation is the maximum and the first NaN in C order wins; otherwise the
 // largest value, the smallest linear index on ties
 __device__ __forceinline__ bool pauli_better(double of, long ofi, double f, long fi) {
@@ -136,6 +130,23 @@ __global__ void __launch_bounds__(256) pauli_final_kernel(const PauliPartial* pa
   pauli_block_reduce(f, fi, forb, &res);
   __syncthreads();
   if (threadIdx.x == 0) { out_vals[0] = res.maxf; out_idx[0] = res.maxidx; out_idx[1] = res.forb; }
+}
+
+// middle stage for the per-wave partials of the fused guard (collision kernels): block b reduces its contiguous share
+__global__ void __launch_bounds__(256) pauli_merge_kernel(const PauliPartial* part, long nparts, PauliPartial* out) {
+  double f = -__builtin_huge_val();
+  long fi = 0x7fffffffffffffffL, forb = -1;
+  const long per = (nparts + gridDim.x - 1) / gridDim.x;
+  const long lo = (long)blockIdx.x * per, hi = lo + per < nparts ? lo + per : nparts;
+  for (long k = lo + threadIdx.x; k < hi; k += blockDim.x) pauli_merge(f, fi, forb, part[k].maxf, part[k].maxidx, part[k].forb);
+  pauli_block_reduce(f, fi, forb, out + blockIdx.x);
+}
+
+void pauli_finish(const PauliPartial* parts, long nparts, PauliPartial* scratch, double* out_vals, long* out_idx,
+                  hipStream_t stream) {
+  hipLaunchKernelGGL(pauli_merge_kernel, dim3(kGuardMergeBlocks), dim3(256), 0, stream, parts, nparts, scratch);
+  hipLaunchKernelGGL(pauli_final_kernel, dim3(1), dim3(256), 0, stream, (const PauliPartial*)scratch, kGuardMergeBlocks,
+                     out_vals, out_idx);
 }
 
 __global__ void __launch_bounds__(256) absmax_partial_kernel(const double* __restrict__ a, long n, double* part) {

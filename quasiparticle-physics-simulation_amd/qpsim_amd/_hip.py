@@ -58,6 +58,10 @@ SIGNATURES = {
     "qp_implicit_sweep": (C.c_int, [C.POINTER(GridDesc), C.c_double, C.c_int, c_dp, c_dp, c_dp, c_dp]),
     "qp_collision_step": (C.c_int, [C.POINTER(CollisionTables), c_dp, C.c_int64, c_dp, c_dp, c_dp, c_dp,
                                     C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, c_dp]),
+    "qp_collision_guard_workspace_bytes": (C.c_int64, [C.c_int64]),
+    "qp_collision_step_guarded": (C.c_int, [C.POINTER(CollisionTables), c_dp, C.c_int64, c_dp, c_dp, c_dp, c_dp,
+                                            C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double, c_dp, c_dp,
+                                            c_dp, c_dp]),
     "qp_euler_collision": (C.c_int, [C.c_int32, C.c_int64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_double, C.c_double,
                                      C.c_int, c_dp]),
     "qp_add_constant": (C.c_int, [c_dp, C.c_int64, C.c_int32, c_dp, C.c_double, c_dp]),

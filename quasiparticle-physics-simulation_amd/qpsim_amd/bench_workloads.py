@@ -17,6 +17,7 @@ from .geometry import extract_edge_segments
 from .models import BoundaryCondition
 
 HBM_PEAK_GBS = 8000.0
+FP64_VECTOR_PEAK_TFLOPS = 78.6     # half of the 157.3 TF fp32 vector peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
 def _rect_engine(N: int, device, nx: int | None = None):
@@ -108,8 +109,11 @@ class ADIWorkload:
         per_sweep_s = ms * 1e-3 / sweeps
         bytes_per_launch = 16.0 * self.cell_updates_per_step         # 8 B read + 8 B write per cell per sweep
         achieved = bytes_per_launch / per_sweep_s / 1e9
+        traffic = self._pmc_traffic()
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": self._pmc_traffic(),
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": None if traffic is None else
+                "profiles/ (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not measured in this run)",
                 "kernel": ("rect_x_kernel / rect_y_kernel (one tile sweep)" if self.op.rect is not None else
                            "tile_x_kernel / tile_y_kernel, clean + general launches of one sweep" if self.op.tile is not None
                            else "thomas_lines_kernel"),
@@ -171,21 +175,29 @@ class CoupledWorkload:
                             f"phonons {'dynamic' if dynamic_phonons else 'frozen'}; reflective walls, D0=6 dt=0.1 dx=1")
         self.max_occ = 0.0
 
-    def _collide(self, dtc):
-        import ctypes as C
-        from . import _hip
+    def _collide(self, dtc, guarded: bool = False):
+        """One collision call over all members; ``guarded``: the Pauli guard of the new state is reduced by the same call
+        (as `run_2d_crank_nicolson` does for the last collision of a step) and a read-back ticket is returned."""
         eng = self.eng
-        acc = None
-        if self.upd and not self.tab["fast"]:
-            acc = eng.scratch("coll_acc", 2 * self.tab["nw"] * self.npix)
-        elif self.upd and self.tab["merged_slots"] and self.en_r and self.en_s:
-            acc = eng.scratch("coll_acc", 2 * self.tab["merged_slots"] * self.npix)
-        _hip.check(eng.lib.qp_collision_step(C.byref(self.tab["struct"]), int(self.coll_flags.data_ptr()), self.npix,
-                                             int(self.state.data_ptr()), int(self.alt.data_ptr()),
-                                             int(self.phonon.data_ptr()), 0 if acc is None else int(acc.data_ptr()),
-                                             float(self.dE), float(dtc), int(self.en_r), int(self.en_s), int(self.upd),
-                                             eng.stream), "qp_collision_step")
+        ticket = None
+        if guarded:
+            ticket = eng.collide_guarded(self.tab, self.state, self.alt, self.phonon, self.dE, dtc, self.en_r, self.en_s,
+                                         self.upd, 1e-18, ncell=self.npix, flags=self.coll_flags)
+        else:
+            import ctypes as C
+            from . import _hip
+            acc = None
+            if self.upd and not self.tab["fast"]:
+                acc = eng.scratch("coll_acc", 2 * self.tab["nw"] * self.npix)
+            elif self.upd and self.tab["merged_slots"] and self.en_r and self.en_s:
+                acc = eng.scratch("coll_acc", 2 * self.tab["merged_slots"] * self.npix)
+            _hip.check(eng.lib.qp_collision_step(C.byref(self.tab["struct"]), int(self.coll_flags.data_ptr()), self.npix,
+                                                 int(self.state.data_ptr()), int(self.alt.data_ptr()),
+                                                 int(self.phonon.data_ptr()), 0 if acc is None else int(acc.data_ptr()),
+                                                 float(self.dE), float(dtc), int(self.en_r), int(self.en_s), int(self.upd),
+                                                 eng.stream), "qp_collision_step")
         self.state, self.alt = self.alt, self.state
+        return ticket
 
     def _guard_launch(self):
         """Pauli guard over all members (device reduction + asynchronous read-back, as `run_2d_crank_nicolson` does)."""
@@ -204,8 +216,7 @@ class CoupledWorkload:
         for _ in range(k):
             self._collide(0.5 * self.dt)
             self.eng.adi_steps(self.op, self.state, 1)
-            self._collide(0.5 * self.dt)
-            ticket = self._guard_launch()
+            ticket = self._collide(0.5 * self.dt, guarded=True)
             if pending is not None:
                 self._guard_check(pending)
             pending = ticket
@@ -239,12 +250,24 @@ class CoupledWorkload:
         per_call = ev0.elapsed_time(ev1) * 1e-3 / nrep
         achieved = self.coll_bytes_per_call / per_call / 1e9
         pairs = self.ne * self.ne
+        flops = 26.0 * pairs * self.npix               # ~26 NE^2 flop per pixel-update
+        tflops = flops / per_call / 1e12
+        kernel = {"register": "collision_diag_kernel" if self.ne < 32 else
+                  "collision_range_kernel x2 + collision_phonon_kernel (one call)", "wave": "collision_wave_kernel",
+                  "generic": "collision_generic_kernel"}[self.tab["kernel"]]
+        traffic, source = self._pmc_traffic(), None
+        if traffic is not None:
+            source = "profiles/r01_c3_pmc.json (committed rocprofv3 --pmc passes of this workload, not measured in this run)"
+        common = {"traffic": traffic, "traffic_source": source, "kernel": kernel, "bytes_per_launch": self.coll_bytes_per_call,
+                  "flops_per_launch": flops, "avg_launch_us": per_call * 1e6, "pixel_updates_per_s": self.npix / per_call,
+                  "hbm_gbs": achieved, "hbm_frac": achieved / HBM_PEAK_GBS, "fp64_tflops": tflops,
+                  "fp64_frac": tflops / FP64_VECTOR_PEAK_TFLOPS,
+                  "note": f"16*(NE+Nw) B per pixel when phonons are dynamic; ~26*NE^2 = {26 * pairs} flop per pixel-update"}
+        if self.ne >= 20:      # 26 NE^2 flop against 16 (NE + Nw) B per pixel: above NE ~ 20 the fp64 vector rate bounds it
+            return {"bound": "fp64", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, **common}
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": self._pmc_traffic(), "kernel": {"register": "collision_diag_kernel", "wave": "collision_wave_kernel",
-                                            "generic": "collision_generic_kernel"}[self.tab["kernel"]],
-                "bytes_per_launch": self.coll_bytes_per_call, "avg_launch_us": per_call * 1e6,
-                "pixel_updates_per_s": self.npix / per_call,
-                "note": f"16*(NE+Nw) B per pixel when phonons are dynamic; ~26*NE^2 = {26 * pairs} flop per pixel-update"}
+                **common}
 
 
 class DecomposedADIWorkload:

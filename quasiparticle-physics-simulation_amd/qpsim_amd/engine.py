@@ -716,6 +716,43 @@ class Engine:
                                               int(bool(en_r)), int(bool(en_s)), int(bool(update_phonons)), self.stream),
                    "qp_collision_step")
 
+    def collide_guarded(self, tables, state, state_out, phonon, dE, dt, en_r, en_s, update_phonons, floor: float,
+                        ncell: int | None = None, flags=None):
+        """``collide`` + the Pauli-guard reduction of ``state_out`` in one library call (``qp_collision_step_guarded``): the
+        single-pass register kernels reduce the statistics of the new densities while they are still in registers.
+        Returns a ticket for ``pauli_stats_result`` (asynchronous read-back, as ``pauli_stats_launch``)."""
+        nc = self.ncell if ncell is None else int(ncell)
+        need_acc = update_phonons and (en_r or en_s) and not tables["fast"]
+        acc = self.scratch("coll_acc", 2 * tables["nw"] * nc) if need_acc else None
+        if tables["kernel"] == "register" and tables["merged_slots"] and update_phonons and en_r and en_s:
+            acc = self.scratch("coll_acc", 2 * tables["merged_slots"] * nc)
+        nbytes = int(self.lib.qp_collision_guard_workspace_bytes(nc))
+        ws = getattr(self, "_guard_ws", None)
+        if ws is None or ws.numel() < nbytes:
+            ws = self._guard_ws = self.torch.empty(nbytes, dtype=self.torch.uint8, device=self.device)
+        hv, hi, ev = self._guard_slot()
+        self._guard_ne = tables["ne"]
+        _hip.check(self.lib.qp_collision_step_guarded(
+            C.byref(tables["struct"]), _ptr(self.d_flags if flags is None else flags), nc, _ptr(state), _ptr(state_out),
+            _ptr(phonon), _ptr(acc), float(dE), float(dt), int(bool(en_r)), int(bool(en_s)), int(bool(update_phonons)),
+            float(floor), _ptr(ws), _ptr(self._red_vals), _ptr(self._red_idx), self.stream), "qp_collision_step_guarded")
+        hv.copy_(self._red_vals, non_blocking=True)
+        hi.copy_(self._red_idx, non_blocking=True)
+        ev.record(self.torch.cuda.current_stream(self.device))
+        return hv, hi, ev, nc
+
+    def _guard_slot(self):
+        """Next of the two pinned read-back slots of the guard (two tickets may be outstanding)."""
+        torch = self.torch
+        if not hasattr(self, "_guard_slots"):
+            self._guard_slots = [(torch.empty(2, dtype=torch.float64).pin_memory(),
+                                  torch.empty(2, dtype=torch.int64).pin_memory(),
+                                  torch.cuda.Event()) for _ in range(2)]
+            self._guard_next = 0
+        slot = self._guard_slots[self._guard_next]
+        self._guard_next ^= 1
+        return slot
+
     def add_constant(self, state, amount: float):
         _hip.check(self.lib.qp_add_constant(_ptr(self.d_flags), self.ncell, state.shape[0], _ptr(state), float(amount),
                                             self.stream), "qp_add_constant")
@@ -732,13 +769,7 @@ class Engine:
         ``pauli_stats_result``.  Two tickets may be outstanding, so a time loop can enqueue the next step before it
         looks at the previous step's guard and the GPU never waits for the host round trip."""
         torch = self.torch
-        if not hasattr(self, "_guard_slots"):
-            self._guard_slots = [(torch.empty(2, dtype=torch.float64).pin_memory(),
-                                  torch.empty(2, dtype=torch.int64).pin_memory(),
-                                  torch.cuda.Event()) for _ in range(2)]
-            self._guard_next = 0
-        hv, hi, ev = self._guard_slots[self._guard_next]
-        self._guard_next ^= 1
+        hv, hi, ev = self._guard_slot()
         nc = self.ncell if ncell is None else int(ncell)
         self._guard_ne = tables["ne"]
         _hip.check(self.lib.qp_pauli_stats(_ptr(state), _ptr(tables["rho"]), _ptr(tables["cls"]),

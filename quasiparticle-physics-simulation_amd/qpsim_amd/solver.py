@@ -553,13 +553,21 @@ def run_2d_crank_nicolson(
     # the reference gates on the raw mode string (solver.py:1459)
     gen_active = external_generation is not None and external_generation.mode != "none"
 
-    def collide(dt_col: float) -> None:
+    def collide(dt_col: float, guard_step=None):
+        """One collision update; with ``guard_step = (step, time)`` the Pauli guard of that step is reduced by the same
+        library call (the collision is then the last operation of the step).  Returns True when the guard was enqueued."""
         nonlocal state, state_alt
         if dt_col <= 0.0 or not collisions:
-            return
-        eng.collide(ctab, state, state_alt, phonon, dE, dt_col, enable_recombination, enable_scattering,
-                    not freeze_phonon_dynamics)
+            return False
+        if guard_step is None:
+            eng.collide(ctab, state, state_alt, phonon, dE, dt_col, enable_recombination, enable_scattering,
+                        not freeze_phonon_dynamics)
+        else:
+            ticket = eng.collide_guarded(ctab, state, state_alt, phonon, dE, dt_col, enable_recombination,
+                                         enable_scattering, not freeze_phonon_dynamics, pauli_density_floor)
+            pending_guard.append((ticket, guard_step[0], guard_step[1]))
         state, state_alt = state_alt, state
+        return guard_step is not None
 
     # Pure diffusion (no collisions, no generation) with a guard that cannot fire (no thresholds, no forbidden bins):
     # nothing but diffusion steps lies between two store points, so the stretch is one call as in scalar mode.
@@ -592,15 +600,18 @@ def run_2d_crank_nicolson(
                 g_ext = evaluate_external_generation(external_generation, E_bins, n, current_time, mask)
                 if g_ext is not None:
                     eng.add_scaled(state, eng.upload_packed(g_ext), dt_step)
+        guarded = False
         if collisions and enable_diffusion:                      # Strang: C(dt/2) D(dt) C(dt/2)
             collide(0.5 * dt_step)
             diffuser.step(state, final)
-            collide(0.5 * dt_step)
+            guarded = collide(0.5 * dt_step, guard_step=(step, current_time + dt_step))
         else:
-            collide(dt_step)
-            if enable_diffusion and dt_step > 0.0:
+            diffuse_after = enable_diffusion and dt_step > 0.0
+            guarded = collide(dt_step, guard_step=None if diffuse_after else (step, current_time + dt_step))
+            if diffuse_after:
                 diffuser.step(state, final)
-        guard_launch(step, current_time + dt_step)
+        if not guarded:
+            guard_launch(step, current_time + dt_step)
         guard_flush(keep=0 if stored(step) else 1)
         current_time += dt_step
         if stored(step):

@@ -299,3 +299,70 @@ def test_store_points_download_asynchronously_and_in_order():
     assert np.array_equal(np.stack(ph_all["phonon_energy_frames"][-1]), np.stack(ph_last["phonon_energy_frames"][-1]),
                           equal_nan=True)
     assert len(ph_all["phonon_frames"]) == 10 and all(np.isfinite(m) for m in every[2])
+
+
+@pytest.mark.parametrize("ne,nclass,mode", [(6, 1, "plain"), (12, 1, "ties"), (12, 1, "forbidden"), (16, 3, "plain"),
+                                            (24, 1, "plain"), (12, 2, "forbidden"), (50, 1, "plain"), (33, 1, "plain")])
+def test_fused_pauli_guard_equals_the_separate_reduction(ne, nclass, mode):
+    """qp_collision_step_guarded (statistics reduced inside the register kernels, one partial per wave) must return exactly
+    what qp_pauli_stats finds in the new state: value, argmax in np.argmax order (ties!), first forbidden index.  Sizes
+    without the fused epilogue (NE >= 32 split kernels, 33 = wave kernel) take the separate pass inside the same call."""
+    from qpsim_amd import tables as T
+    from qpsim_amd.engine import CompiledGeometry, Engine, link_flags
+    rng = np.random.default_rng(ne * 3 + nclass)
+    mask = rng.random((37, 53)) > 0.25                 # 1961 cells: neither a multiple of 64 nor of 128; ~25 % inactive
+    z = np.zeros(mask.shape)
+    eng = Engine(CompiledGeometry(mask, 1.0, link_flags(mask), z, z, z, z))
+    n = int(mask.sum())
+    gaps = np.array([180.0, 171.0, 165.5])[:nclass]
+    E, dE = T.build_energy_grid(180.0, 1.0, 3.0 if ne <= 24 else 10.0, ne)
+    om, idx_d, idx_s, sg = T.build_phonon_frequency_map(E)
+    rho = np.stack([T.dynes_density_of_states(E, g, 0.1) for g in gaps])
+    kr = np.stack([T.recombination_kernel_base(E, g, 500.0, 1.2) for g in gaps])
+    ks = np.stack([T.scattering_kernel_base(E, g, 400.0, 1.2) for g in gaps])
+    cls = rng.integers(0, nclass, size=n)
+    state = rng.random((ne, n)) * rho[cls].T * rng.choice([1e-5, 1e-2, 0.5, 0.9], size=n)[None, :]
+    if mode == "forbidden":                            # a bin without states that nevertheless holds density
+        rho[:, 2] = 0.0
+        state[2, :] = 0.0
+        state[2, [n // 3, n // 2]] = 1e-6
+    if mode == "ties":                                 # identical pixels: the same occupation twice, the first index wins
+        state[:, 700] = state[:, 40]
+        state[:, 41] = state[:, 40]
+        state[:, 40] *= 0.97 / np.max(state[:, 40] / rho[0])   # near-full occupation: they stay the maximum after the update
+        state[:, 41] = state[:, 40]
+        state[:, 700] = state[:, 40]
+    ph = T.thermal_phonon_occupation(om, 0.3)[:, None] * (0.5 + rng.random((om.size, n)))
+    if mode == "ties":
+        ph[:, 41] = ph[:, 40]
+        ph[:, 700] = ph[:, 40]
+    tab = eng.make_collision_tables(kr, ks, rho, idx_d, idx_s, sg, cls if nclass > 1 else None,
+                                    gap_params=dict(E=E, gaps=gaps, tau_r=500.0, tau_s=400.0, T_c=1.2))
+    if ne in (6, 12, 16, 24):
+        assert tab["kernel"] == "register"
+    res = {}
+    for fused in (False, True):
+        s_in, p_dev = eng.upload_packed(state), eng.upload_packed(ph)
+        s_out = eng.empty(ne, eng.ncell)
+        if fused:
+            ticket = eng.collide_guarded(tab, s_in, s_out, p_dev, dE, 0.2, True, True, True, 1e-18)
+            stats = eng.pauli_stats_result(ticket)
+        else:
+            eng.collide(tab, s_in, s_out, p_dev, dE, 0.2, True, True, True)
+            stats = eng.pauli_stats(s_out, tab, 1e-18)
+        res[fused] = (stats, eng.download_packed(s_out), eng.download_packed(p_dev))
+    assert np.array_equal(res[True][1], res[False][1]) and np.array_equal(res[True][2], res[False][2])
+    assert res[True][0] == res[False][0], (res[True][0], res[False][0])
+    mx, top, forb = res[True][0]
+    out = res[True][1]
+    f = np.where(rho[cls].T > 1e-30, out / np.maximum(rho[cls].T, 1e-30), 0.0)
+    cell_of_px = np.flatnonzero(mask.reshape(-1))
+    k = int(np.argmax(f))
+    assert mx == f.reshape(-1)[k] and top == (k // n, cell_of_px[k % n])
+    if mode == "forbidden":
+        assert forb is not None and forb[0] == 2 and forb[1] == cell_of_px[n // 3]
+    else:
+        assert forb is None
+    if mode == "ties":         # the three identical pixels give identical results; among them the first index must win
+        assert np.array_equal(out[:, 40], out[:, 41]) and np.array_equal(out[:, 40], out[:, 700])
+        assert top[1] == cell_of_px[40], "the identical pixels carry the maximum by construction"
