@@ -268,9 +268,8 @@ constexpr int kTileHasBc = 1 << 30;      // tile-list entry: (has_bc << 30) | (t
 // STREAM >= 0: stream mode known at compile time (clean tiles: the bandwidth-bound kernels keep branch-free accesses);
 // STREAM < 0: taken from the plan at run time (general tiles are issue-bound, one variant suffices)
 template <int CLS, int STREAM>
-__device__ __forceinline__ TileCoord tile_of(const TileView& v, bool& has_bc) {
+__device__ __forceinline__ TileCoord tile_of(const TileView& v, int id, bool& has_bc) {
   TileCoord t;
-  const int id = blockIdx.x;
   t.b = id % v.nfield;                          // fields of one tile are neighbours in launch order: shared codes hit L2
   // the list entry is wave-uniform; say so, or every row address of the tile becomes a per-lane 64-bit value
   const int packed = __builtin_amdgcn_readfirstlane(v.tiles[CLS == 0 ? 0 : 1][id / v.nfield]);
@@ -383,13 +382,12 @@ __device__ __forceinline__ auto clean_coefs(const TileView& v, int b, int lane, 
 }
 
 // x-kernel: finish the x-solve, [apply (I + a Lx) . + a S], store, chunk-local eliminations along y -> iface[1]
-template <int CLS, bool EXPLICIT, int STREAM, bool COMPACT = false>
-__global__ void __launch_bounds__(64) tile_x_kernel(TileView v, double* __restrict__ buf) {
-  __shared__ double lds[LDS_DOUBLES];
-  extern __shared__ double bct[];
+template <int CLS, bool EXPLICIT, int STREAM, bool COMPACT>
+__device__ __forceinline__ void tile_x_body(const TileView& v, double* __restrict__ buf, double* lds, double* bct,
+                                            int block) {
   const int lane = threadIdx.x;
   bool has_bc;
-  const TileCoord t = tile_of<CLS, STREAM>(v, has_bc);
+  const TileCoord t = tile_of<CLS, STREAM>(v, block, has_bc);
   if (CLS != 0) stage_bct(v, bct, lane);
   const long ncell = (long)v.ny * v.nx;
   double* plane = buf + (long)t.b * ncell;
@@ -426,16 +424,35 @@ __global__ void __launch_bounds__(64) tile_x_kernel(TileView v, double* __restri
   }
 }
 
+template <int CLS, bool EXPLICIT, int STREAM, bool COMPACT = false>
+__global__ void __launch_bounds__(64) tile_x_kernel(TileView v, double* __restrict__ buf) {
+  __shared__ double lds[LDS_DOUBLES];
+  extern __shared__ double bct[];
+  tile_x_body<CLS, EXPLICIT, STREAM, COMPACT>(v, buf, lds, bct, blockIdx.x);
+}
+
+// One launch for both classes: the general tiles first (they take longest), the clean tiles behind them.  For plans with
+// FEW general tiles (a ring in 4096^2: 328 single-wave blocks for 1024 SIMDs) two launches in a row leave the chip
+// two-thirds idle for the whole general launch; merged, the general path's register footprint (one wave per SIMD) applies
+// to the clean tiles as well, which costs them less than the idle launch did (ring in 4096^2: 55 -> 45 us per sweep).
+template <bool EXPLICIT>
+__global__ void __launch_bounds__(64) tile_x_merged_kernel(TileView v, double* __restrict__ buf) {
+  __shared__ double lds[LDS_DOUBLES];
+  extern __shared__ double bct[];
+  const int ngen = v.ntiles[1] * v.nfield;
+  if ((int)blockIdx.x < ngen) tile_x_body<1, EXPLICIT, -1, false>(v, buf, lds, bct, blockIdx.x);
+  else tile_x_body<0, EXPLICIT, 0, true>(v, buf, lds, bct, blockIdx.x - ngen);
+}
+
 // y-kernel.  MODE 0 (entry): src = u -> rhs1 = (I + a Ly) u + a S;  MODE 1 (carry): y-solve, rhs1' of the next step;
 //            MODE 2 (exit): y-solve, dst = u';  MODE 3 (reduce): only the x-eliminations of src (nothing stored).
 //            MODE 0, 1, 3 end with the chunk-local eliminations along x -> iface[0]
-template <int CLS, int MODE, int STREAM, bool COMPACT = false>
-__global__ void __launch_bounds__(64) tile_y_kernel(TileView v, const double* src, double* dst) {   // src may alias dst
-  __shared__ double lds[LDS_DOUBLES];
-  extern __shared__ double bct[];
+template <int CLS, int MODE, int STREAM, bool COMPACT>
+__device__ __forceinline__ void tile_y_body(const TileView& v, const double* src, double* dst, double* lds, double* bct,
+                                            int block) {   // src may alias dst
   const int lane = threadIdx.x;
   bool has_bc;
-  const TileCoord t = tile_of<CLS, STREAM>(v, has_bc);
+  const TileCoord t = tile_of<CLS, STREAM>(v, block, has_bc);
   if (CLS != 0) stage_bct(v, bct, lane);
   const long ncell = (long)v.ny * v.nx;
   const double* splane = src + (long)t.b * ncell;
@@ -482,6 +499,22 @@ __global__ void __launch_bounds__(64) tile_y_kernel(TileView v, const double* sr
     ir[(long)(2 * t.tx + 1) * v.ny + t.j0 + lane] = yf;
     ir[(long)(2 * t.tx + 2) * v.ny + t.j0 + lane] = yl;
   }
+}
+
+template <int CLS, int MODE, int STREAM, bool COMPACT = false>
+__global__ void __launch_bounds__(64) tile_y_kernel(TileView v, const double* src, double* dst) {
+  __shared__ double lds[LDS_DOUBLES];
+  extern __shared__ double bct[];
+  tile_y_body<CLS, MODE, STREAM, COMPACT>(v, src, dst, lds, bct, blockIdx.x);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(64) tile_y_merged_kernel(TileView v, const double* src, double* dst) {   // see tile_x_merged_kernel
+  __shared__ double lds[LDS_DOUBLES];
+  extern __shared__ double bct[];
+  const int ngen = v.ntiles[1] * v.nfield;
+  if ((int)blockIdx.x < ngen) tile_y_body<1, MODE, -1, false>(v, src, dst, lds, bct, blockIdx.x);
+  else tile_y_body<0, MODE, 0, true>(v, src, dst, lds, bct, blockIdx.x - ngen);
 }
 
 // Plan creation: interface coefficients (s, t) of every chunk of every non-empty tile in both directions, and the
@@ -579,6 +612,7 @@ struct qp_adi_tile_plan {
   // the clean tiles) go to a side stream, forked from and joined to the caller's stream with events around every sweep.
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool merged = false;             // few general tiles: one launch for both classes (tile_x_merged_kernel)
 };
 
 extern "C" {
@@ -770,6 +804,11 @@ static int tile_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, co
     return QP_ERR_UNSUPPORTED;
   }
   {
+    const char* m = getenv("QPSIM_TILE_MERGE");
+    const bool few = (long)v.ntiles[1] * nfield <= 1024;
+    plan->merged = v.ntiles[0] > 0 && v.ntiles[1] > 0 && !var && v.stream == 0 && v.compact && (m ? atoi(m) != 0 : few);
+  }
+  {
     // opt-in (QPSIM_TILE_FORK=1): measured on MI355X the event fork / join costs more than the overlap gains for one field
     // (ring in 4096^2: 0.113 -> 0.131 ms per step) and gains 4 % for four fields
     const char* e = getenv("QPSIM_TILE_FORK");
@@ -828,6 +867,11 @@ static void join_general(const qp_adi_tile_plan* plan, hipStream_t stream) {
 template <bool EXPLICIT>
 static void launch_x(const qp_adi_tile_plan* plan, double* buf, hipStream_t stream) {
   const TileView& v = plan->view;
+  if (plan->merged) {
+    hipLaunchKernelGGL((tile_x_merged_kernel<EXPLICIT>), dim3((unsigned)((long)(v.ntiles[0] + v.ntiles[1]) * v.nfield)),
+                       dim3(64), plan->bct_bytes, stream, v, buf);
+    return;
+  }
   const hipStream_t gstream = fork_general(plan, stream);
   if (v.ntiles[0] > 0) {
     const dim3 grid((unsigned)((long)v.ntiles[0] * v.nfield));
@@ -853,6 +897,11 @@ static void launch_x(const qp_adi_tile_plan* plan, double* buf, hipStream_t stre
 template <int MODE>
 static void launch_y(const qp_adi_tile_plan* plan, const double* src, double* dst, hipStream_t stream) {
   const TileView& v = plan->view;
+  if (plan->merged) {
+    hipLaunchKernelGGL((tile_y_merged_kernel<MODE>), dim3((unsigned)((long)(v.ntiles[0] + v.ntiles[1]) * v.nfield)),
+                       dim3(64), plan->bct_bytes, stream, v, src, dst);
+    return;
+  }
   const hipStream_t gstream = fork_general(plan, stream);
   if (v.ntiles[0] > 0) {
     const dim3 grid((unsigned)((long)v.ntiles[0] * v.nfield));
