@@ -199,6 +199,7 @@ def strong_scaling_record(args, dev, world: int, rank: int) -> dict:
     no_xchg = timed_steps(wl, args.steps, dev, True, exchange=False)      # same kernels, refreshes skipped: timing only
     return {
         "workload": wl.description, "path": wl.path, "scaling": "strong", "rccl_ranks": dist.get_world_size(),
+        "backend": dist.get_backend(),
         "value": float(N) * N * args.steps / elapsed, "unit": "cell-updates/s", "ms_per_step": 1e3 * elapsed / args.steps,
         "one_rank_ms_per_step": 1e3 * one_rank / args.steps, "speedup_vs_one_rank": one_rank / elapsed,
         "exchange_share_of_time": max(0.0, 1.0 - no_xchg / elapsed), "steps_per_halo_refresh": spe,
@@ -228,13 +229,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
+    # Rehearsal knobs (not used by the driver): QPSIM_BENCH_BACKEND=gloo and QPSIM_BENCH_DEVICE=0 let several ranks share one
+    # GPU with gloo as the transport, which exercises the whole N > 1 code path where RCCL (one rank per GPU) cannot run.
+    backend = os.environ.get("QPSIM_BENCH_BACKEND", "nccl")
+    device_index = int(os.environ.get("QPSIM_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(device_index)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    dev = torch.device("cuda", device_index)
 
     from qpsim_amd import bench_workloads as W
 

@@ -215,7 +215,8 @@ int qp_absmax(const double* a, int64_t n, void* workspace, double* out_val, void
 
 /* y[i] += alpha * x[i] */
 int qp_axpy(int64_t n, double alpha, const double* x, double* y, void* stream);
-/* y[i] = alpha * x[i] + beta * y[i]   (direction update of the Chebyshev-accelerated exact-CN iteration) */
+/* y[i] = alpha * x[i] + beta * y[i]; with beta == 0 y is not read (it may be uninitialised)
+ * (direction update of the Chebyshev-accelerated exact-CN iteration) */
 int qp_axpby(int64_t n, double alpha, const double* x, double beta, double* y, void* stream);
 
 /*

@@ -58,7 +58,7 @@ struct PauliPartial {
   long maxidx;
   long forb;
 };
-constexpr int kGuardMergeBlocks = 64;
+constexpr int kGuardMergeBlocks = 512;
 // reduces `nparts` partials (written by the collision kernels, one per wave) to out_vals[0], out_idx[0..1];
 // `scratch` holds kGuardMergeBlocks partials
 void pauli_finish(const PauliPartial* parts, long nparts, PauliPartial* scratch, double* out_vals, long* out_idx,

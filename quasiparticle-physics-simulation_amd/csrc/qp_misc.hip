@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(256) axpy_kernel(long n, double alpha, const d
 __global__ void __launch_bounds__(256) axpby_kernel(long n, double alpha, const double* __restrict__ x, double beta,
                                                     double* __restrict__ y) {
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x)
-    y[t] = fma(alpha, x[t], beta * y[t]);
+    y[t] = beta == 0.0 ? alpha * x[t] : fma(alpha, x[t], beta * y[t]);      // beta = 0: y may hold anything (NaN too)
 }
 
 static inline unsigned grid_for(long n) {

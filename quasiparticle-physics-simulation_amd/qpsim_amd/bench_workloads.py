@@ -79,17 +79,18 @@ class ADIWorkload:
         prof = Path(__file__).resolve().parents[2] / "profiles"
         if self.N != 4096 or self.nfield != 1:
             return None
-        if self.op.rect is not None and (prof / "r01_adi4096_pmc_v3.json").exists():
-            k = json.loads((prof / "r01_adi4096_pmc_v3.json").read_text())["kernels"]
-            pick = lambda frag: sum(v["hbm_bytes_per_launch"] for name, v in k.items() if frag in name)  # noqa: E731
-            return 0.5 * (pick("rect_x_kernel<true, 0>") + pick("rect_y_kernel<1, 0>"))
-        if self.ring and self.op.tile is not None and (prof / "r01_ring4096_pmc.json").exists():
-            k = json.loads((prof / "r01_ring4096_pmc.json").read_text())["kernels"]
-            pick = lambda frag: sum(v["hbm_bytes_per_launch"] for name, v in k.items() if frag in name)  # noqa: E731
-            # one sweep = clean + general launch; average of the x sweep and the carried y sweep
-            return 0.5 * (pick("tile_x_kernel<0, true>") + pick("tile_x_kernel<1, true>") + pick("tile_y_kernel<0, 1>")
-                          + pick("tile_y_kernel<1, 1>"))
-        return None
+        name = "r02_ring4096_pmc.json" if self.ring else "r02_adi4096_pmc.json"
+        if not (prof / name).exists():
+            return None
+        k = json.loads((prof / name).read_text())["kernels"]
+        pick = lambda frag: sum(v["hbm_bytes_per_launch"] for n_, v in k.items() if frag in n_)  # noqa: E731
+        if self.op.rect is not None:
+            val = 0.5 * (pick("rect_x_kernel<true, 0, true>") + pick("rect_y_kernel<1, 0, true>"))
+        elif self.op.tile is not None:      # one sweep = one merged launch (clean + general tiles); mean of x and carried y
+            val = 0.5 * (pick("tile_x_merged_kernel<true>") + pick("tile_y_merged_kernel<1>"))
+        else:
+            return None
+        return val or None
 
     def roofline(self, nrep: int) -> dict:
         """Average duration of one sweep kernel launch (HIP events on the launch stream) vs algorithmic bytes."""
@@ -113,7 +114,8 @@ class ADIWorkload:
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": None if traffic is None else
-                "profiles/ (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not measured in this run)",
+                "profiles/r02_*_pmc.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not measured "
+                "in this run)",
                 "kernel": ("rect_x_kernel / rect_y_kernel (one tile sweep)" if self.op.rect is not None else
                            "tile_x_kernel / tile_y_kernel, clean + general launches of one sweep" if self.op.tile is not None
                            else "thomas_lines_kernel"),
@@ -227,11 +229,11 @@ class CoupledWorkload:
         """HBM bytes per collision call from the committed PMC summary of `--workload c3` (profiles/r01_c3_pmc.json)."""
         import json
         from pathlib import Path
-        f = Path(__file__).resolve().parents[2] / "profiles" / "r01_c3_pmc.json"
+        f = Path(__file__).resolve().parents[2] / "profiles" / "r02_c3_pmc.json"
         if not (self.N == 4096 and self.ne == 12 and self.members == 1 and self.upd and self.en_s and f.exists()):
             return None
         for name, v in json.loads(f.read_text())["kernels"].items():
-            if "collision_diag_kernel<12, true, true, true>" in name:
+            if "collision_diag_kernel<12, true, true, true, false>" in name:
                 return v["hbm_bytes_per_launch"]
         return None
 
@@ -257,7 +259,7 @@ class CoupledWorkload:
                   "generic": "collision_generic_kernel"}[self.tab["kernel"]]
         traffic, source = self._pmc_traffic(), None
         if traffic is not None:
-            source = "profiles/r01_c3_pmc.json (committed rocprofv3 --pmc passes of this workload, not measured in this run)"
+            source = "profiles/r02_c3_pmc.json (committed rocprofv3 --pmc passes of this workload, not measured in this run)"
         common = {"traffic": traffic, "traffic_source": source, "kernel": kernel, "bytes_per_launch": self.coll_bytes_per_call,
                   "flops_per_launch": flops, "avg_launch_us": per_call * 1e6, "pixel_updates_per_s": self.npix / per_call,
                   "hbm_gbs": achieved, "hbm_frac": achieved / HBM_PEAK_GBS, "fp64_tflops": tflops,

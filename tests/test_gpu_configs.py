@@ -176,6 +176,7 @@ def test_exact_cn_on_stiff_steps_converges_by_chebyshev_or_raises(O, ny, nx, D):
     assert op.r * D > 2.5
     u0 = np.random.default_rng(ny).random((2, ny * nx))
     v = eng.upload_packed(u0)
+    eng.scratch("cn_d", 2 * ny * nx).fill_(float("nan"))      # the direction buffer starts uninitialised: must not matter
     its = eng.cn_exact_step(op, v)
     ops = O.build_grid_ops(mask, edges, bcs, dx)
     got = eng.download_packed(v)
