@@ -343,14 +343,20 @@ class OverlapDecomposedWorkload:
     (``distributed.halo_steps_bound``); ``coupled=True`` adds the collision half-steps (full physics, NE = 12) on the
     decomposed grid.  Strong scaling: the global grid is fixed."""
 
-    def __init__(self, N: int, device, coupled: bool = False, steps_per_exchange=None):
+    def __init__(self, N: int, device, coupled: bool = False, steps_per_exchange=None, topo=None):
+        """``topo``: a ``BlockTopology`` makes this the block of one VIRTUAL rank (several of them in one process, driven by
+        ``distributed.lockstep_overlap_steps``: tests on one GPU); default: the rank of this process in torch.distributed."""
         import torch.distributed as dist
         from .distributed import BlockTopology, HipOverlapBlock, OverlapBlock, TorchDistTransport, choose_process_grid
-        self.world = dist.get_world_size() if dist.is_initialized() else 1
-        rank = dist.get_rank() if dist.is_initialized() else 0
-        py, px = choose_process_grid(self.world, N, N)
-        self.topo = BlockTopology(N, N, py, px, rank)
-        self.transport = TorchDistTransport() if self.world > 1 else None
+        if topo is None:
+            self.world = dist.get_world_size() if dist.is_initialized() else 1
+            rank = dist.get_rank() if dist.is_initialized() else 0
+            py, px = choose_process_grid(self.world, N, N)
+            self.topo = BlockTopology(N, N, py, px, rank)
+            self.transport = TorchDistTransport() if self.world > 1 else None
+        else:
+            self.topo, self.world, self.transport = topo, topo.py * topo.px, None
+            py, px = topo.py, topo.px
         self.coupled = coupled
         j0, i0, ny, nx = self.topo.block
         if not coupled:
