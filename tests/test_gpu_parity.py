@@ -16,8 +16,13 @@ STRIP_TOL = 1e-10   # north_star: parity <= 1e-10 rel on the MKID cross-check (s
 GRID_TOL = 1e-9     # 2-D grids, exact-CN mode iterated to 1e-13 residual
 ADI_TOL = 1e-11     # HIP ADI vs the oracle's ADI restatement (same algorithm, fp64 rounding only)
 # phonon occupations go through (e^{b dt} - 1)/b of solver.py:697 (no expm1): for small |b dt| a last-bit difference
-# between the host and device exp() is amplified by eps/|b dt|, so phonon planes get a looser same-algorithm bound
-PHONON_TOL = 1e-9
+# between the host and device exp() is amplified by eps/|b dt|.  Priced in tests/test_gpu_configs.py against an 80-bit
+# evaluation of the same algorithm: the fp64 reference restatement and the HIP kernels both sit ~1e-11 from it (NE = 12: 1.3e-11,
+# NE = 50: 1.2e-11) and much closer to each other, so the kernel-vs-oracle bound is north_star's 1e-10 (round 1 used 1e-9)
+PHONON_TOL = 1e-10
+# whole runs accumulate that conditioning over their steps (mkid_24x24_ne12_full_physics: 20 coupled steps): phonon HISTORIES
+# of multi-step runs keep the round-1 bound
+RUN_PHONON_TOL = 1e-9
 # (recombination, scattering, update_phonons): every template instantiation of the register kernels, including the
 # frozen-phonon single-process ones the BASELINE configs[1] workload (`bench.py --workload c2`) runs
 PROCESS_COMBOS = [(True, True, True), (True, False, True), (False, True, True), (True, True, False), (True, False, False),
@@ -209,7 +214,7 @@ def test_adi_scheme_matches_oracle_adi_on_2d(O, name):
         assert rel_err(np.stack([np.stack(t) for t in got[4]]), np.stack([np.stack(t) for t in ref[4]])) < ADI_TOL
     if ph is not None and ph["phonon_energy_frames"] is not None:
         assert rel_err(np.stack([np.stack(t) for t in ph["phonon_energy_frames"]]),
-                       np.stack([np.stack(t) for t in ref[6]["phonon_energy_frames"]])) < PHONON_TOL
+                       np.stack([np.stack(t) for t in ref[6]["phonon_energy_frames"]])) < RUN_PHONON_TOL
 
 
 def test_mkid_crosscheck_bound_of_the_reference_test():
