@@ -14,7 +14,7 @@ QP_DIAG_NE_LIST(QP_DECLARE_DIAG)
 #define QP_DIAGP_NE_LIST(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
 QP_DIAGP_NE_LIST(QP_DEFINE_DIAGP)
 // ... and the single-pass sizes of the other units
-#define QP_DIAGP_NE_LIST_EXT(X) X(18) X(20) X(24) X(30)
+#define QP_DIAGP_NE_LIST_EXT(X) X(18) X(20) X(24) X(30) X(32) X(40) X(50)
 #define QP_DECLARE_DIAGP(N)                                                                                               \
   void diag_launcherp_##N##_11(const CollFastView&, const uint8_t*, long, const double*, double*, double*, double, double, \
                                bool, hipStream_t);                                                                         \
@@ -71,7 +71,8 @@ bool collision_fast_dispatch_classes(int ne, const double* rho, const int* cls, 
                                      double guard_floor, bool* guard_done, hipStream_t stream) {
   if (guard_done) *guard_done = false;
   if (ncell >= (1L << 28)) return false;
-  CollFastView v{nullptr, nullptr, rho, diag_bin, anti_bin, stash, cls, gap_sq, kr_amp, ks_amp, pair_inv, guard, guard_floor};
+  CollFastView v{nullptr, nullptr, rho, diag_bin, anti_bin, stash, cls, gap_sq, kr_amp, ks_amp, pair_inv,
+                 ne < 32 ? guard : nullptr, guard_floor};
   const bool s = en_s && ks_amp, r = en_r && kr_amp, u = upd && (s || r);
   if (!s && !r) return false;
   diag_launcher_t fn = nullptr;
@@ -83,7 +84,7 @@ bool collision_fast_dispatch_classes(int ne, const double* rho, const int* cls, 
     default: return false;
   }
   fn(v, flags, ncell, sin_, sout, ph, dE, dt, u, stream);
-  if (guard_done) *guard_done = guard != nullptr;
+  if (guard_done) *guard_done = v.guard != nullptr;
   return true;
 }
 

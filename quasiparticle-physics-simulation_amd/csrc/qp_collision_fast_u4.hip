@@ -5,4 +5,5 @@ namespace qp {
 QP_DEFINE_DIAG(30)
 QP_DEFINE_DIAG(32)
 QP_DEFINE_DIAGP(30)
+QP_DEFINE_DIAGP(32)
 }  // namespace qp

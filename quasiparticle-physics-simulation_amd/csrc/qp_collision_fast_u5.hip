@@ -3,4 +3,5 @@
 
 namespace qp {
 QP_DEFINE_DIAG(40)
+QP_DEFINE_DIAGP(40)
 }  // namespace qp

@@ -131,10 +131,11 @@ class CoupledWorkload:
     """
 
     def __init__(self, N, device, *, ne=12, recombination=True, scattering=True, dynamic_phonons=True, label="",
-                 members=1, fmax=3.0, nx=None, init_occupation=None):
+                 members=1, fmax=3.0, nx=None, init_occupation=None, gap_classes=1):
         """``members`` independent N x N problems are batched: planes are laid out [bin][member][cell], so the ADI plan
         sees NE*members fields of N x N and the collision kernel sees members*N*N pixels (no coupling between members).
-        ``nx``: N x nx rectangle instead of a square; ``init_occupation``: device tensor [N*nx] replacing the seeded field."""
+        ``nx``: N x nx rectangle instead of a square; ``init_occupation``: device tensor [N*nx] replacing the seeded field;
+        ``gap_classes`` > 1: non-uniform gap (one gap value per block of columns, 0.9 gap ... gap), collision tables per class."""
         self.N, self.nfield, self.ne, self.members = N, ne * members, ne, members
         NX = N if nx is None else int(nx)
         self.eng = eng = _rect_engine(N, device, NX)
@@ -146,9 +147,18 @@ class CoupledWorkload:
         om, idx_d, idx_s, sg = T.build_phonon_frequency_map(E)
         self.nw = om.size
         rho = T.dynes_density_of_states(E, gap, 0.0)
-        kr = T.recombination_kernel_base(E, gap, 440.0, 1.2)[None] if recombination else None
-        ks = T.scattering_kernel_base(E, gap, 440.0, 1.2)[None] if scattering else None
-        self.tab = eng.make_collision_tables(kr, ks, rho[None], idx_d, idx_s, sg)
+        if gap_classes > 1:
+            gaps = np.linspace(0.9 * gap, gap, gap_classes)
+            cls = np.tile((np.arange(NX) * gap_classes) // NX, N * members)
+            rho_c = np.stack([T.dynes_density_of_states(E, g, 0.0) for g in gaps])
+            kr = np.stack([T.recombination_kernel_base(E, g, 440.0, 1.2) for g in gaps]) if recombination else None
+            ks = np.stack([T.scattering_kernel_base(E, g, 440.0, 1.2) for g in gaps]) if scattering else None
+            self.tab = eng.make_collision_tables(kr, ks, rho_c, idx_d, idx_s, sg, cls,
+                                                 gap_params=dict(E=E, gaps=gaps, tau_r=440.0, tau_s=440.0, T_c=1.2))
+        else:
+            kr = T.recombination_kernel_base(E, gap, 440.0, 1.2)[None] if recombination else None
+            ks = T.scattering_kernel_base(E, gap, 440.0, 1.2)[None] if scattering else None
+            self.tab = eng.make_collision_tables(kr, ks, rho[None], idx_d, idx_s, sg)
         self.en_r, self.en_s, self.upd = recombination, scattering, dynamic_phonons
         w = rho / (np.sum(rho) * dE)
         npix = members * N * NX
@@ -461,8 +471,10 @@ def build(name: str, device):
     if name == "c3":
         return CoupledWorkload(4096, device, recombination=True, scattering=True, dynamic_phonons=True,
                                label="BASELINE configs[2]: ")
-    m = re.fullmatch(r"coupled(\d+)(?:ne(\d+))?", name)
-    if m:   # coupled<N>[ne<NE>]: full physics on N x N with NE energy bins (ne50 = the reference's default resolution)
+    m = re.fullmatch(r"coupled(\d+)(?:ne(\d+))?(?:gap(\d+))?", name)
+    if m:   # coupled<N>[ne<NE>][gap<K>]: full physics on N x N with NE energy bins (ne50 = the reference's default
+        # resolution), K gap classes (non-uniform gap; collisions only - the diffusivity stays uniform)
         ne = int(m.group(2) or 12)
-        return CoupledWorkload(int(m.group(1)), device, ne=ne, fmax=3.0 if ne <= 24 else 10.0)
+        return CoupledWorkload(int(m.group(1)), device, ne=ne, fmax=3.0 if ne <= 24 else 10.0,
+                               gap_classes=int(m.group(3) or 1))
     raise ValueError(f"unknown workload '{name}'")

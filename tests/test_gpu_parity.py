@@ -670,7 +670,7 @@ def test_collision_kernel_selection():
     assert pick(20, 3.0) == "register" and pick(33, 10.0) == "wave" and pick(64, 10.0) == "wave"   # 33, 64: no instantiation
     assert pick(17, 3.0) == "wave"             # rounding splits some |Ei-Ej| into extra bins here: no diagonal structure
     assert pick(18, 10.0) == "register"        # merged bins: register kernel with the scratch stash
-    assert pick(12, 3.0, nclass=2) == "wave"   # gap classes
+    assert pick(12, 3.0, nclass=2) == "wave"   # gap classes without the separable tables (gap_params)
     assert pick(65, 10.0) == "generic"
 
 
@@ -968,7 +968,8 @@ def test_tiled_paths_agree_with_per_line_kernels_on_random_geometries(seed):
     assert rel_err(eng.download_packed(a), eng.download_packed(b)) < 5e-13
 
 
-@pytest.mark.parametrize("ne,fmax", [(6, 3.0), (12, 3.0), (12, 5.0), (16, 10.0), (24, 3.0), (30, 3.0)])
+@pytest.mark.parametrize("ne,fmax", [(6, 3.0), (12, 3.0), (12, 5.0), (16, 10.0), (24, 3.0), (30, 3.0), (32, 3.0), (40, 5.0),
+                                     (50, 10.0)])
 @pytest.mark.parametrize("en_r,en_s,upd", PROCESS_COMBOS)
 def test_register_collision_kernel_with_gap_classes(O, ne, fmax, en_r, en_s, upd):
     """Non-uniform gap (per-pixel K_r0_all / K_s0_all / rho_all of solver.py:1203-1232): the register kernel forms K per
