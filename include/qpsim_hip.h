@@ -215,6 +215,9 @@ int qp_absmax(const double* a, int64_t n, void* workspace, double* out_val, void
 
 /* y[i] += alpha * x[i] */
 int qp_axpy(int64_t n, double alpha, const double* x, double* y, void* stream);
+/* d[i] = c1 * z[i] + c2 * d[i] (d not read when c2 == 0); v[i] += d[i]: direction + iterate update of the Chebyshev
+ * iteration in one pass */
+int qp_cheb_update(int64_t n, double c1, const double* z, double c2, double* d, double* v, void* stream);
 /* y[i] = alpha * x[i] + beta * y[i]; with beta == 0 y is not read (it may be uninitialised)
  * (direction update of the Chebyshev-accelerated exact-CN iteration) */
 int qp_axpby(int64_t n, double alpha, const double* x, double beta, double* y, void* stream);
@@ -244,6 +247,12 @@ int qp_adi_rect_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, co
 int qp_adi_rect_plan_destroy(qp_adi_rect_plan* plan);
 int qp_adi_rect_plan_decoupled(const qp_adi_rect_plan* plan, int32_t dir);
 int qp_adi_rect_steps(qp_adi_rect_plan* plan, double* u, int32_t nsteps, void* stream);
+/* qp_stencil_combine for the plan's operator without per-cell geometry arrays (positions decide which side term applies):
+ * out = c0 u + cx (a Lx u) + cy (a Ly u) + cs a S + cr rin on [nfield][ny*nx]; with norm_out non-NULL also
+ * norm_out[0] = max |out| (workspace: qp_pauli_workspace_bytes() bytes), which saves the exact-CN iteration its
+ * separate norm pass.  (1,1,1,2,0) = CN right-hand side, (-1,1,1,0,1) = residual rin - (I - a L) u. */
+int qp_adi_rect_combine(qp_adi_rect_plan* plan, const double* u, const double* rin, double* out, double c0, double cx,
+                        double cy, double cs, double cr, void* workspace, double* norm_out, void* stream);
 /* x[nfield][ny*nx] <- (I - a Ly)^-1 (I - a Lx)^-1 x in place: the ADI factorisation applied as the preconditioner of
  * the exact Crank-Nicolson iteration (replaces two qp_implicit_sweep calls on full rectangles). */
 int qp_adi_rect_solve(qp_adi_rect_plan* plan, double* x, void* stream);

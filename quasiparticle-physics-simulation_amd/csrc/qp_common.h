@@ -64,6 +64,9 @@ constexpr int kGuardMergeBlocks = 512;
 void pauli_finish(const PauliPartial* parts, long nparts, PauliPartial* scratch, double* out_vals, long* out_idx,
                   hipStream_t stream);
 
+// out[0] = max over `nparts` per-block maxima (second stage of qp_absmax, shared with qp_adi_rect_combine)
+void absmax_finish(const double* parts, int nparts, double* out, hipStream_t stream);
+
 // Harmonic-mean face diffusivity (solver.py:283).
 __device__ __forceinline__ double face_mean(double dp, double dq) {
   return 2.0 * dp * dq / fmax(dp + dq, 1e-30);

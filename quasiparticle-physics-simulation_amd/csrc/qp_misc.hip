@@ -179,6 +179,20 @@ __global__ void __launch_bounds__(256) absmax_final_kernel(const double* part, i
   if (threadIdx.x == 0) out[0] = sm[0];
 }
 
+void absmax_finish(const double* parts, int nparts, double* out, hipStream_t stream) {
+  hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, stream, parts, nparts, out);
+}
+
+// direction and iterate update of the Chebyshev iteration in one pass: d = c1 z + c2 d (d not read when c2 == 0), v += d
+__global__ void __launch_bounds__(256) cheb_update_kernel(long n, double c1, const double* __restrict__ z, double c2,
+                                                          double* __restrict__ d, double* __restrict__ v) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+    const double dn = c2 == 0.0 ? c1 * z[t] : fma(c1, z[t], c2 * d[t]);
+    d[t] = dn;
+    v[t] += dn;
+  }
+}
+
 __global__ void __launch_bounds__(256) axpy_kernel(long n, double alpha, const double* __restrict__ x,
                                                    double* __restrict__ y) {
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x)
@@ -272,6 +286,12 @@ int qp_axpy(int64_t n, double alpha, const double* x, double* y, void* stream) {
   QP_REQUIRE(x && y && n > 0, "bad arguments");
   hipLaunchKernelGGL(qp::axpy_kernel, dim3(qp::grid_for(n)), dim3(256), 0, (hipStream_t)stream, (long)n, alpha, x, y);
   return qp::check_launch("qp_axpy");
+}
+
+int qp_cheb_update(int64_t n, double c1, const double* z, double c2, double* d, double* v, void* stream) {
+  QP_REQUIRE(z && d && v && n > 0, "bad arguments");
+  hipLaunchKernelGGL(qp::cheb_update_kernel, dim3(qp::grid_for(n)), dim3(256), 0, (hipStream_t)stream, (long)n, c1, z, c2, d, v);
+  return qp::check_launch("qp_cheb_update");
 }
 
 int qp_axpby(int64_t n, double alpha, const double* x, double beta, double* y, void* stream) {

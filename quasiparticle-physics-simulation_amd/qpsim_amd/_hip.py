@@ -73,6 +73,9 @@ SIGNATURES = {
     "qp_weighted_sum": (C.c_int, [c_dp, c_dp, C.c_int32, C.c_int64, c_dp, c_dp]),
     "qp_absmax": (C.c_int, [c_dp, C.c_int64, c_dp, c_dp, c_dp]),
     "qp_axpy": (C.c_int, [C.c_int64, C.c_double, c_dp, c_dp, c_dp]),
+    "qp_cheb_update": (C.c_int, [C.c_int64, C.c_double, c_dp, C.c_double, c_dp, c_dp, c_dp]),
+    "qp_adi_rect_combine": (C.c_int, [C.POINTER(RectPlan), c_dp, c_dp, c_dp, C.c_double, C.c_double, C.c_double,
+                                      C.c_double, C.c_double, c_dp, c_dp, c_dp]),
     "qp_axpby": (C.c_int, [C.c_int64, C.c_double, c_dp, C.c_double, c_dp, c_dp]),
     "qp_adi_rect_plan_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.POINTER(C.c_double),
                                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32,

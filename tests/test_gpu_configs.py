@@ -367,3 +367,28 @@ def test_fused_pauli_guard_equals_the_separate_reduction(ne, nclass, mode):
     if mode == "ties":         # the three identical pixels give identical results; among them the first index must win
         assert np.array_equal(out[:, 40], out[:, 41]) and np.array_equal(out[:, 40], out[:, 700])
         assert top[1] == cell_of_px[40], "the identical pixels carry the maximum by construction"
+
+
+@pytest.mark.parametrize("ny,nx", [(70, 130), (1, 100), (64, 1), (3, 5)])
+def test_rect_combine_equals_the_general_stencil(ny, nx):
+    """qp_adi_rect_combine (operator from the plan's four side terms, norm fused) vs qp_stencil_combine (per-cell geometry
+    arrays) for every coefficient set the exact-CN iteration uses, plus the fused max-norm."""
+    import torch
+    from qpsim_amd.engine import DiffusionOperator, Engine, compile_geometry
+    mask, edges, bcs = _rect_problem(ny, nx)
+    eng = Engine(compile_geometry(mask, edges, bcs, 0.9))
+    rect = DiffusionOperator(eng, 3, 0.11, dcoef=[6.0, 0.35, 0.0])
+    gen = DiffusionOperator(eng, 3, 0.11, dcoef=[6.0, 0.35, 0.0], allow_fast=False)
+    assert rect.rect is not None and gen.rect is None
+    g = torch.Generator(device=eng.device).manual_seed(ny + nx)
+    u = torch.rand((3, ny * nx), dtype=torch.float64, device=eng.device, generator=g)
+    rin = torch.rand((3, ny * nx), dtype=torch.float64, device=eng.device, generator=g)
+    for coef, use_rin in (((1.0, 1.0, 1.0, 2.0, 0.0), False), ((-1.0, 1.0, 1.0, 0.0, 1.0), True),
+                          ((1.0, 0.0, 1.0, 1.0, 0.0), False), ((0.5, -0.25, 2.0, 1.0, -3.0), True)):
+        a, b = eng.empty(3, ny * nx), eng.empty(3, ny * nx)
+        norm = eng.empty(1)
+        eng.stencil(rect, u, a, *coef[:4], rin=rin if use_rin else None, cr=coef[4], norm_out=norm)
+        eng.stencil(gen, u, b, *coef[:4], rin=rin if use_rin else None, cr=coef[4])
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 4e-15 * scale
+        assert float(norm.item()) == float(a.abs().max())
