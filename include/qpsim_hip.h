@@ -81,6 +81,12 @@ typedef struct qp_grid_desc {
  */
 int qp_stencil_combine(const qp_grid_desc* g, double r, const double* u, const double* rin, double* out,
                        double c0, double cx, double cy, double cs, double cr, void* stream);
+/* The same with norm_out[0] = max |out| formed in the same pass (NaN counts as +inf; workspace:
+ * qp_pauli_workspace_bytes() bytes): the residual and its norm of the exact-CN iteration in one kernel.
+ * ex, ey, sx, sy are read only at cells with a missing link - boundary terms belong to boundary faces. */
+int qp_stencil_combine_norm(const qp_grid_desc* g, double r, const double* u, const double* rin, double* out,
+                            double c0, double cx, double cy, double cs, double cr, void* workspace, double* norm_out,
+                            void* stream);
 
 /*
  * Implicit sweep: solve (I - r L_dir) x = rhs along every grid line of every field (dir 0 = x, 1 = y).
@@ -215,12 +221,9 @@ int qp_absmax(const double* a, int64_t n, void* workspace, double* out_val, void
 
 /* y[i] += alpha * x[i] */
 int qp_axpy(int64_t n, double alpha, const double* x, double* y, void* stream);
-/* d[i] = c1 * z[i] + c2 * d[i] (d not read when c2 == 0); v[i] += d[i]: direction + iterate update of the Chebyshev
- * iteration in one pass */
+/* d[i] = c1 * z[i] + c2 * d[i] (d is not read when c2 == 0: it may be uninitialised); v[i] += d[i]: direction and iterate
+ * update of the Chebyshev-accelerated exact-CN iteration in one pass */
 int qp_cheb_update(int64_t n, double c1, const double* z, double c2, double* d, double* v, void* stream);
-/* y[i] = alpha * x[i] + beta * y[i]; with beta == 0 y is not read (it may be uninitialised)
- * (direction update of the Chebyshev-accelerated exact-CN iteration) */
-int qp_axpby(int64_t n, double alpha, const double* x, double beta, double* y, void* stream);
 
 /*
  * Fast CN-ADI path: full ny x nx rectangle, one diffusivity per field, one boundary condition per side.

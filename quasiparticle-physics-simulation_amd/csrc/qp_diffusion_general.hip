@@ -41,31 +41,54 @@ int validate_grid(const qp_grid_desc* g, const char* who) {
 // ---------------------------------------------------------------------------------------------------------
 // out = c0 u + cx r Lx u + cy r Ly u + cs r D (sx + sy) + cr rin
 // ---------------------------------------------------------------------------------------------------------
+// A block walks (field, row) pairs, its threads the cells of the row (no 64-bit division per cell).  Boundary terms are
+// read only where a link is missing - they belong to boundary faces, and a cell with all four links has none - which
+// saves 32 of the 57 B per cell this kernel moved on masks that are mostly interior.  `part` non-NULL: every block leaves
+// max |out| of its cells there (NaN propagates as +inf).
 __global__ void __launch_bounds__(256) stencil_combine_kernel(GridView g, double r, const double* __restrict__ u,
                                                               const double* __restrict__ rin,
                                                               double* __restrict__ out, double c0, double cx,
-                                                              double cy, double cs, double cr) {
+                                                              double cy, double cs, double cr, double* __restrict__ part) {
   const long ncell = (long)g.ny * g.nx;
-  const long total = ncell * g.nfield;
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-    const int b = (int)(t / ncell);
-    const long p = t - (long)b * ncell;
-    const unsigned f = g.flags[p];
-    double res = 0.0;
-    if (f & QP_FLAG_ACTIVE) {
-      const double* ub = u + (long)b * ncell;
-      const double up = ub[p];
-      const double dp = cell_d(g, b, p, ncell);
-      double lx = -g.ex[p] * dp * up;
-      double ly = -g.ey[p] * dp * up;
-      if (f & QP_FLAG_LINK_XM) lx += face_d(g, b, p, p - 1, ncell, dp) * (ub[p - 1] - up);
-      if (f & QP_FLAG_LINK_XP) lx += face_d(g, b, p, p + 1, ncell, dp) * (ub[p + 1] - up);
-      if (f & QP_FLAG_LINK_YM) ly += face_d(g, b, p, p - g.nx, ncell, dp) * (ub[p - g.nx] - up);
-      if (f & QP_FLAG_LINK_YP) ly += face_d(g, b, p, p + g.nx, ncell, dp) * (ub[p + g.nx] - up);
-      res = c0 * up + cx * (r * lx) + cy * (r * ly) + cs * (r * dp * (g.sx[p] + g.sy[p]));
-      if (rin) res += cr * rin[t];
+  double m = 0.0;
+  for (int line = blockIdx.x; line < g.nfield * g.ny; line += gridDim.x) {
+    const int b = line / g.ny, j = line - b * g.ny;
+    const double* ub = u + (long)b * ncell;
+    for (int i = threadIdx.x; i < g.nx; i += blockDim.x) {
+      const long p = (long)j * g.nx + i;
+      const long t = (long)b * ncell + p;
+      const unsigned f = g.flags[p];
+      double res = 0.0;
+      if (f & QP_FLAG_ACTIVE) {
+        const double up = ub[p];
+        const double dp = cell_d(g, b, p, ncell);
+        double lx = 0.0, ly = 0.0, src = 0.0;
+        if ((f & 15u) != 15u) {
+          lx = -g.ex[p] * dp * up;
+          ly = -g.ey[p] * dp * up;
+          src = g.sx[p] + g.sy[p];
+        }
+        if (f & QP_FLAG_LINK_XM) lx += face_d(g, b, p, p - 1, ncell, dp) * (ub[p - 1] - up);
+        if (f & QP_FLAG_LINK_XP) lx += face_d(g, b, p, p + 1, ncell, dp) * (ub[p + 1] - up);
+        if (f & QP_FLAG_LINK_YM) ly += face_d(g, b, p, p - g.nx, ncell, dp) * (ub[p - g.nx] - up);
+        if (f & QP_FLAG_LINK_YP) ly += face_d(g, b, p, p + g.nx, ncell, dp) * (ub[p + g.nx] - up);
+        res = c0 * up + cx * (r * lx) + cy * (r * ly) + cs * (r * dp * src);
+        if (rin) res += cr * rin[t];
+      }
+      out[t] = res;
+      const double v = fabs(res);
+      m = (v != v) ? __builtin_huge_val() : fmax(m, v);
     }
-    out[t] = res;
+  }
+  if (part) {
+    __shared__ double sm[256];
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sm[0];
   }
 }
 
@@ -126,19 +149,27 @@ int qp_version(void) { return 200; }
 
 const char* qp_last_error(void) { return qp::g_err; }
 
-int qp_stencil_combine(const qp_grid_desc* g, double r, const double* u, const double* rin, double* out, double c0,
-                       double cx, double cy, double cs, double cr, void* stream) {
+int qp_stencil_combine_norm(const qp_grid_desc* g, double r, const double* u, const double* rin, double* out, double c0,
+                            double cx, double cy, double cs, double cr, void* workspace, double* norm_out, void* stream) {
   int rc = qp::validate_grid(g, "qp_stencil_combine");
   if (rc) return rc;
   QP_REQUIRE(u && out, "u and out must be non-NULL");
   QP_REQUIRE(rin || cr == 0.0, "rin is NULL but cr != 0");
   QP_REQUIRE(u != out, "u and out must not alias (neighbour reads)");
-  const long total = (long)g->ny * g->nx * g->nfield;
-  long blocks = (total + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
+  QP_REQUIRE(norm_out == nullptr || workspace, "workspace is required with norm_out");
+  long blocks = (long)g->ny * g->nfield;
+  const long cap = norm_out ? 1024 : 8192;           // with a norm: the partial slots of the reduction workspace
+  if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(qp::stencil_combine_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                     qp::make_view(g), r, u, cr == 0.0 ? nullptr : rin, out, c0, cx, cy, cs, cr);
+                     qp::make_view(g), r, u, cr == 0.0 ? nullptr : rin, out, c0, cx, cy, cs, cr,
+                     norm_out ? (double*)workspace : nullptr);
+  if (norm_out) qp::absmax_finish((const double*)workspace, (int)blocks, norm_out, (hipStream_t)stream);
   return qp::check_launch("qp_stencil_combine");
+}
+
+int qp_stencil_combine(const qp_grid_desc* g, double r, const double* u, const double* rin, double* out, double c0,
+                       double cx, double cy, double cs, double cr, void* stream) {
+  return qp_stencil_combine_norm(g, r, u, rin, out, c0, cx, cy, cs, cr, nullptr, nullptr, stream);
 }
 
 int qp_implicit_sweep(const qp_grid_desc* g, double r, int dir, const double* rhs, double* x, double* scratch,

@@ -199,12 +199,6 @@ __global__ void __launch_bounds__(256) axpy_kernel(long n, double alpha, const d
     y[t] += alpha * x[t];
 }
 
-__global__ void __launch_bounds__(256) axpby_kernel(long n, double alpha, const double* __restrict__ x, double beta,
-                                                    double* __restrict__ y) {
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x)
-    y[t] = beta == 0.0 ? alpha * x[t] : fma(alpha, x[t], beta * y[t]);      // beta = 0: y may hold anything (NaN too)
-}
-
 static inline unsigned grid_for(long n) {
   long b = (n + 255) / 256;
   return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
@@ -292,12 +286,6 @@ int qp_cheb_update(int64_t n, double c1, const double* z, double c2, double* d, 
   QP_REQUIRE(z && d && v && n > 0, "bad arguments");
   hipLaunchKernelGGL(qp::cheb_update_kernel, dim3(qp::grid_for(n)), dim3(256), 0, (hipStream_t)stream, (long)n, c1, z, c2, d, v);
   return qp::check_launch("qp_cheb_update");
-}
-
-int qp_axpby(int64_t n, double alpha, const double* x, double beta, double* y, void* stream) {
-  QP_REQUIRE(x && y && n > 0, "bad arguments");
-  hipLaunchKernelGGL(qp::axpby_kernel, dim3(qp::grid_for(n)), dim3(256), 0, (hipStream_t)stream, (long)n, alpha, x, beta, y);
-  return qp::check_launch("qp_axpby");
 }
 
 }  // extern "C"

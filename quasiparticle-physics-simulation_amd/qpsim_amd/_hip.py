@@ -55,6 +55,8 @@ SIGNATURES = {
     "qp_last_error": (C.c_char_p, []),
     "qp_stencil_combine": (C.c_int, [C.POINTER(GridDesc), C.c_double, c_dp, c_dp, c_dp, C.c_double, C.c_double,
                                      C.c_double, C.c_double, C.c_double, c_dp]),
+    "qp_stencil_combine_norm": (C.c_int, [C.POINTER(GridDesc), C.c_double, c_dp, c_dp, c_dp, C.c_double, C.c_double,
+                                          C.c_double, C.c_double, C.c_double, c_dp, c_dp, c_dp]),
     "qp_implicit_sweep": (C.c_int, [C.POINTER(GridDesc), C.c_double, C.c_int, c_dp, c_dp, c_dp, c_dp]),
     "qp_collision_step": (C.c_int, [C.POINTER(CollisionTables), c_dp, C.c_int64, c_dp, c_dp, c_dp, c_dp,
                                     C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, c_dp]),
@@ -76,7 +78,6 @@ SIGNATURES = {
     "qp_cheb_update": (C.c_int, [C.c_int64, C.c_double, c_dp, C.c_double, c_dp, c_dp, c_dp]),
     "qp_adi_rect_combine": (C.c_int, [C.POINTER(RectPlan), c_dp, c_dp, c_dp, C.c_double, C.c_double, C.c_double,
                                       C.c_double, C.c_double, c_dp, c_dp, c_dp]),
-    "qp_axpby": (C.c_int, [C.c_int64, C.c_double, c_dp, C.c_double, c_dp, c_dp]),
     "qp_adi_rect_plan_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.POINTER(C.c_double),
                                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32,
                                           C.POINTER(C.POINTER(RectPlan))]),

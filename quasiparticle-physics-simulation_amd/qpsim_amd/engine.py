@@ -463,17 +463,16 @@ class Engine:
     # -- diffusion --------------------------------------------------------------------------------------------
     def stencil(self, op: DiffusionOperator, u, out, c0, cx, cy, cs, rin=None, cr=0.0, norm_out=None):
         """out = c0 u + cx rLx u + cy rLy u + cs rD S + cr rin; with ``norm_out`` (device scalar) also max |out|.  Full
-        rectangles with one boundary condition per side use the plan's own operator (no per-cell geometry arrays, norm
-        fused); other geometries the general kernel plus, if asked for, the separate norm pass."""
+        rectangles with one boundary condition per side use the plan's own operator (no per-cell geometry arrays); other
+        geometries the general kernel (boundary terms read only at boundary cells); the norm is formed in the same pass."""
         if op.rect is not None:
             _hip.check(self.lib.qp_adi_rect_combine(op.rect.handle, _ptr(u), _ptr(rin), _ptr(out), c0, cx, cy, cs, cr,
                                                     _ptr(self._ws) if norm_out is not None else 0, _ptr(norm_out),
                                                     self.stream), "qp_adi_rect_combine")
             return
-        _hip.check(self.lib.qp_stencil_combine(C.byref(op.desc), op.r, _ptr(u), _ptr(rin), _ptr(out), c0, cx, cy, cs,
-                                               cr, self.stream), "qp_stencil_combine")
-        if norm_out is not None:
-            self._absmax_into(out, norm_out)
+        _hip.check(self.lib.qp_stencil_combine_norm(C.byref(op.desc), op.r, _ptr(u), _ptr(rin), _ptr(out), c0, cx, cy, cs,
+                                                    cr, _ptr(self._ws) if norm_out is not None else 0, _ptr(norm_out),
+                                                    self.stream), "qp_stencil_combine")
 
     def sweep(self, op: DiffusionOperator, direction: int, rhs, x):
         scr = self.scratch("thomas", 2 * op.nfield * self.ncell)
