@@ -222,18 +222,17 @@ class CoupledWorkload:
         self.max_occ = max(self.max_occ, mx)
 
     def run(self, k: int):
-        """k steps; the guard of step s is read on the host after step s+1 has been enqueued (every step is checked,
-        the last one before returning)."""
-        pending = None
+        """k steps; the guard of step s is read on the host after step s + GUARD_LAG has been enqueued (every step is
+        checked, the last ones before returning) - as `run_2d_crank_nicolson` does."""
+        pending = []
         for _ in range(k):
             self._collide(0.5 * self.dt)
             self.eng.adi_steps(self.op, self.state, 1)
-            ticket = self._collide(0.5 * self.dt, guarded=True)
-            if pending is not None:
-                self._guard_check(pending)
-            pending = ticket
-        if pending is not None:
-            self._guard_check(pending)
+            pending.append(self._collide(0.5 * self.dt, guarded=True))
+            while len(pending) > self.eng.GUARD_LAG:
+                self._guard_check(pending.pop(0))
+        for ticket in pending:
+            self._guard_check(ticket)
 
     def _pmc_traffic(self):
         """HBM bytes per collision call from the committed PMC summary of `--workload c3` (profiles/r01_c3_pmc.json)."""

@@ -459,9 +459,9 @@ def run_2d_crank_nicolson(
     cell_to_px = np.cumsum(eng.mask_flat) - 1
     warned = False
 
-    # The guard of step k is enqueued right after the step and examined after step k+1 has been enqueued (or before
-    # anything is stored / returned), so the device does not idle during the host round trip.  Messages carry the
-    # step / time of the step that was checked, exactly as the reference's.
+    # The guard of step k is enqueued right after the step and examined after step k + GUARD_LAG has been enqueued (or
+    # before anything is stored / returned), so the device does not idle during the host round trip and the host never
+    # sleeps on an event.  Messages carry the step / time of the step that was checked, exactly as the reference's.
     pending_guard: list = []
 
     def guard_launch(step_idx: int, time_ns: float) -> None:
@@ -612,7 +612,7 @@ def run_2d_crank_nicolson(
                 diffuser.step(state, final)
         if not guarded:
             guard_launch(step, current_time + dt_step)
-        guard_flush(keep=0 if stored(step) else 1)
+        guard_flush(keep=0 if stored(step) else eng.GUARD_LAG)
         current_time += dt_step
         if stored(step):
             times.append(float(current_time))
