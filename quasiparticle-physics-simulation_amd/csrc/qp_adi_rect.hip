@@ -165,8 +165,14 @@ __device__ __forceinline__ void ghost_finish(const RectView& v, int b, int p, bo
 // x-kernel: finish the x-solve, apply the explicit x-operator, eliminate along y.   buf: rhs1 -> rhs2 in place
 // ---------------------------------------------------------------------------------------------------------
 // EXPLICIT = false is the plain solve (I - a Lx)^-1 used by the exact-CN preconditioner: no explicit operator, no sources.
+#ifdef QP_FORCE_WAVES      // occupancy experiments (tools/ablate.sh): waves per SIMD forced through the register budget
+#define QP_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(QP_FORCE_WAVES, QP_FORCE_WAVES)))
+#else
+#define QP_WAVES_ATTR
+#endif
+
 template <bool EXPLICIT, int STREAM, bool COMPACT>
-__global__ void __launch_bounds__(64) rect_x_kernel(RectView v, double* __restrict__ buf) {
+__global__ void __launch_bounds__(64) QP_WAVES_ATTR rect_x_kernel(RectView v, double* __restrict__ buf) {
   __shared__ double lds[LDS_DOUBLES];
   const int lane = threadIdx.x;
   const TileCoord t = tile_coord<STREAM>(v.d);
@@ -213,7 +219,7 @@ __global__ void __launch_bounds__(64) rect_x_kernel(RectView v, double* __restri
 //            MODE 3 (reduce): src = rhs of an x-solve; only its reduced right-hand sides are formed (nothing stored)
 // ---------------------------------------------------------------------------------------------------------
 template <int MODE, int STREAM, bool COMPACT>
-__global__ void __launch_bounds__(64) rect_y_kernel(RectView v, const double* src, double* dst) {  // src may alias dst
+__global__ void __launch_bounds__(64) QP_WAVES_ATTR rect_y_kernel(RectView v, const double* src, double* dst) {  // src may alias dst
   __shared__ double lds[LDS_DOUBLES];
   const int lane = threadIdx.x;
   const TileCoord t = tile_coord<STREAM>(v.d);
