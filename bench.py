@@ -33,6 +33,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 from pathlib import Path
 
@@ -60,6 +61,8 @@ def parse_args():
     ap.add_argument("--force-subrecords", action="store_true",
                     help="emit the sub-records with one rank too (with --force-dist: rehearsal of the N > 1 code path)")
     ap.add_argument("--strong-size", type=int, default=8192, help="grid edge of the strong-scaling sub-record")
+    ap.add_argument("--subrecord-timeout", type=float, default=420.0,
+                    help="seconds after which unfinished N > 1 sub-records are reported as errors and the line printed")
     return ap.parse_args()
 
 
@@ -275,12 +278,35 @@ def main():
     torch.cuda.empty_cache()
     if (world > 1 or (args.force_subrecords and use_dist)) and not args.no_subrecords and args.workload == "adi4096":
         # north_star's two multi-GPU figures, measured in the same run and reported next to the weak-scaling headline
-        result["strong"] = strong_scaling_record(args, dev, world, rank)
-        result["ensemble"] = ensemble_record(args, dev, world)
+        # The headline above is complete at this point; the sub-records must not be able to lose it.  An exception in
+        # one becomes its "error" field, and if a rank gets stuck in them (a peer died, a collective that never returns)
+        # every rank's watchdog ends its process after `--subrecord-timeout` seconds, rank 0 printing the line first.
+        printed = threading.Event()
+
+        def watchdog():
+            if rank == 0 and not printed.is_set():
+                printed.set()
+                for key in ("strong", "ensemble"):
+                    result.setdefault(key, {"error": f"not finished within {args.subrecord_timeout:.0f} s"})
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+
+        timer = threading.Timer(args.subrecord_timeout + (0.0 if rank == 0 else 5.0), watchdog)
+        timer.daemon = True
+        timer.start()
+        for key, fn in (("strong", lambda: strong_scaling_record(args, dev, world, rank)),
+                        ("ensemble", lambda: ensemble_record(args, dev, world))):
+            try:
+                result[key] = fn()
+            except Exception as exc:      # noqa: BLE001 - reported in the line, the headline stays valid
+                result[key] = {"error": f"{type(exc).__name__}: {exc}"}
+        timer.cancel()
+        if printed.is_set():              # the watchdog fired between the last record and cancel()
+            return
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0 would hold the others up)
             result["cpu_baseline"] = cpu_baseline(args, args.workload)
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -31,9 +31,18 @@ __global__ void __launch_bounds__(128) copy_planes_batched(const double* __restr
 #pragma unroll
     for (int k = 0; k < VEC; ++k) __builtin_nontemporal_store(v[i][k] * 1.0000001, &out[(long)i * ncell + p + k]);
 }
-int main() {
+__global__ void fill(double* a, long n) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x)
+    a[t] = 1e-4 * (1.0 + 1e-3 * (double)((t * 2654435761u) % 1000));
+}
+// The rate depends on the data (see tools/tile_ceiling.hip): argument "zero" copies an all-zero buffer (what round 1
+// measured: 5.99 TB/s flat), the default a buffer of ordinary numbers.
+int main(int argc, char** argv) {
   const long ncell = 4096L * 4096; const int np = 47;
   double *in, *out; hipMalloc(&in, ncell * np * 8); hipMalloc(&out, ncell * np * 8); hipMemset(in, 0, ncell * np * 8);
+  const bool zero = argc > 1 && argv[1][0] == 'z';
+  if (!zero) { fill<<<8192, 256>>>(in, ncell * np); hipDeviceSynchronize(); }
+  printf("data: %s\n", zero ? "all zero" : "1e-4 (1 + hash)");
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   auto timeit = [&](const char* name, auto launch) {
     launch(); hipDeviceSynchronize(); hipEventRecord(e0); for (int r = 0; r < 5; ++r) launch(); hipEventRecord(e1); hipEventSynchronize(e1);

@@ -1,7 +1,7 @@
 // What a kernel with the ADI sweeps' access pattern can reach on one MI355X, without their arithmetic:
 //   hipcc --offload-arch=gfx950 -O3 tools/tile_ceiling.hip -o /tmp/tile_ceiling && /tmp/tile_ceiling
 // One wave per ROWS x 64 tile of an N x N fp64 plane: ROWS row-segment loads of 512 B (lane <-> column), all loads before
-// all stores (the solve needs the whole chunk), in place.  Variants: tile height 64 / 32 / 16, waves per SIMD forced
+// all stores (the solve needs the whole chunk), in place, after a warm-up that brings the clocks to their sustained state.  Variants: tile height 64 / 32 / 16, waves per SIMD forced
 // through the register budget, cached vs non-temporal accesses.  Prints the time of one pass and 16 N^2 B / time.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -17,9 +17,9 @@ tile_rmw(double* __restrict__ a, int n, int tiles_x) {
   // a dependent chain through all rows, like the forward / backward substitution (keeps loads before stores)
   double s = 0.0;
 #pragma unroll
-  for (int r = 0; r < ROWS; ++r) { s = fma(s, 0.25, v[r]); v[r] = s; }
+  for (int r = 0; r < ROWS; ++r) { s = fma(s, 0.25, 0.75 * v[r]); v[r] = s; }      // a smoothing recurrence: values stay O(input)
 #pragma unroll
-  for (int r = ROWS - 1; r >= 0; --r) { s = fma(s, 0.25, v[r]); v[r] = s; }
+  for (int r = ROWS - 1; r >= 0; --r) { s = fma(s, 0.25, 0.75 * v[r]); v[r] = s; }
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
     if (NT & 2) __builtin_nontemporal_store(v[r], p + (long)r * n);
@@ -47,22 +47,35 @@ static void run(double* a, int n, const char* tag) {
          16.0 * n * n / us / 1e6);
 }
 
-int main() {
+__global__ void fill(double* a, long n, double scale) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x)
+    a[t] = scale * (1.0 + 1e-3 * (double)((t * 2654435761u) % 1000));
+}
+
+// The rate depends on the DATA: an all-zero plane runs 14 % faster than a plane of ordinary numbers (36.7 vs 41.8 us at
+// 4096^2, reproducibly, whatever ran before) - zero data is what hipMemset leaves and what a quick micro-benchmark
+// measures.  Argument "zero" reproduces that; the default fills the plane with 1e-4 (1 + hash), like the benchmark fields.
+int main(int argc, char** argv) {
   double* a;
   const long nmax = 16384;
   hipMalloc(&a, nmax * nmax * 8);
   hipMemset(a, 0, nmax * nmax * 8);
+  const bool zero = argc > 1 && argv[1][0] == 'z';
+  if (!zero) fill<<<8192, 256>>>(a, nmax * nmax, 1e-4);
+  printf("data: %s\n", zero ? "all zero" : "1e-4 (1 + hash)");
+  // half a second of the same work first: the first milliseconds after an idle period run at boost clocks and read ~13 %
+  // faster (36.4 vs 41.7 us at 4096^2) than the sustained rate every real time loop sees
+  for (int r = 0; r < 12000; ++r) tile_rmw<64, 0, 2><<<4096, 64>>>(a, 4096, 64);
+  hipDeviceSynchronize();
   const int sizes[] = {1024, 2048, 2880, 4096, 5760, 8192, 16384};
   for (int n : sizes) {
     run<64, 0, 2>(a, n, "cached");
     run<64, 2, 2>(a, n, "nt-st");
     run<64, 3, 2>(a, n, "nt-both");
-    run<64, 0, 3>(a, n, "cached");
     run<32, 0, 2>(a, n, "cached");
     run<32, 0, 4>(a, n, "cached");
     run<32, 2, 4>(a, n, "nt-st");
     run<32, 3, 4>(a, n, "nt-both");
-    run<32, 0, 6>(a, n, "cached");
     run<16, 0, 8>(a, n, "cached");
     run<16, 3, 8>(a, n, "nt-both");
     printf("\n");
