@@ -249,6 +249,10 @@ int qp_adi_rect_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, co
                             qp_adi_rect_plan** out);
 int qp_adi_rect_plan_destroy(qp_adi_rect_plan* plan);
 int qp_adi_rect_plan_decoupled(const qp_adi_rect_plan* plan, int32_t dir);
+/* 1 when the plan runs its passes on fine tiles (lines cut into 32-cell chunks, one wave per 32 x 64 / 64 x 32 tile:
+ * undecomposed grids whose extents are multiples of 64, r*D <~ 0.32 for every field, size rule or QPSIM_FINE_TILES=1),
+ * 0 for the 64 x 64 tiles.  Same results to rounding (the dropped far couplings are < 1e-22 either way). */
+int qp_adi_rect_plan_fine(const qp_adi_rect_plan* plan);
 int qp_adi_rect_steps(qp_adi_rect_plan* plan, double* u, int32_t nsteps, void* stream);
 /* qp_stencil_combine for the plan's operator without per-cell geometry arrays (positions decide which side term applies):
  * out = c0 u + cx (a Lx u) + cy (a Ly u) + cs a S + cr rin on [nfield][ny*nx]; with norm_out non-NULL also

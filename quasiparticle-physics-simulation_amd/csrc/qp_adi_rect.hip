@@ -304,10 +304,10 @@ __global__ void __launch_bounds__(64) rect_reduced_kernel(RectView v, int dir) {
 // ---------------------------------------------------------------------------------------------------------
 // host side: tables, plan
 // ---------------------------------------------------------------------------------------------------------
-static void chunk_diagonal(const DirSpec& s, double a, int p, int len, std::vector<double>& bdiag) {
+static void chunk_diagonal(const DirSpec& s, double a, int p, int L, int len, std::vector<double>& bdiag) {
   bdiag.assign(len, 0.0);
   for (int k = 0; k < len; ++k) {
-    const int gk = p * TS + k;
+    const int gk = p * L + k;
     const double links = (gk > 0 ? 1.0 : 0.0) + (gk < s.n - 1 ? 1.0 : 0.0);
     const double e = (gk == 0 ? s.e_lo : 0.0) + (gk == s.n - 1 ? s.e_hi : 0.0);
     bdiag[k] = 1.0 + a * (links + e);
@@ -326,44 +326,45 @@ static void solve_chunk(const std::vector<double>& bdiag, double a, std::vector<
   for (int k = len - 2; k >= 0; --k) rhs[k] += a * w[k] * rhs[k + 1];
 }
 
-void build_chunk_table(const DirSpec& s, double a, int p, double* tab, double ends[4]) {
-  const int len = std::min(TS, s.n - p * TS);
+// table of chunk p of a line cut into chunks of L cells (L = TS for the 64 x 64 tiles, FS for the fine tiles): [T_NSLOT][L]
+void build_chunk_table_len(const DirSpec& s, double a, int p, int L, double* tab, double ends[4]) {
+  const int len = std::min(L, s.n - p * L);
   std::vector<double> bd;
-  chunk_diagonal(s, a, p, len, bd);
-  for (int k = 0; k < TS * T_NSLOT; ++k) tab[k] = 0.0;
+  chunk_diagonal(s, a, p, L, len, bd);
+  for (int k = 0; k < L * T_NSLOT; ++k) tab[k] = 0.0;
   double wprev = 0.0;
-  for (int k = 0; k < TS; ++k) {
+  for (int k = 0; k < L; ++k) {
     if (k < len) {
       const double w = 1.0 / (bd[k] - (k > 0 ? a * a * wprev : 0.0));
-      tab[T_W * TS + k] = w;
-      tab[T_AWF * TS + k] = k > 0 ? a * w : 0.0;
-      tab[T_AWB * TS + k] = k < len - 1 ? a * w : 0.0;
+      tab[T_W * L + k] = w;
+      tab[T_AWF * L + k] = k > 0 ? a * w : 0.0;
+      tab[T_AWB * L + k] = k < len - 1 ? a * w : 0.0;
       wprev = w;
-      const int gk = p * TS + k;
+      const int gk = p * L + k;
       const bool lm = gk > 0, lp = gk < s.n - 1;
       const double e = (gk == 0 ? s.e_lo : 0.0) + (gk == s.n - 1 ? s.e_hi : 0.0);
-      tab[T_CM * TS + k] = lm ? a : 0.0;
-      tab[T_CP * TS + k] = lp ? a : 0.0;
-      tab[T_C0 * TS + k] = 1.0 - a * ((lm ? 1.0 : 0.0) + (lp ? 1.0 : 0.0) + e);
-      tab[T_SRC * TS + k] = a * ((gk == 0 ? s.s_lo : 0.0) + (gk == s.n - 1 ? s.s_hi : 0.0));
+      tab[T_CM * L + k] = lm ? a : 0.0;
+      tab[T_CP * L + k] = lp ? a : 0.0;
+      tab[T_C0 * L + k] = 1.0 - a * ((lm ? 1.0 : 0.0) + (lp ? 1.0 : 0.0) + e);
+      tab[T_SRC * L + k] = a * ((gk == 0 ? s.s_lo : 0.0) + (gk == s.n - 1 ? s.s_hi : 0.0));
     } else {
-      tab[T_W * TS + k] = 1.0;
+      tab[T_W * L + k] = 1.0;
     }
   }
   // elimination slots: forward sweep = the LU pivots again, but padded entries pass the value through; backward sweep =
   // the UL pivots v_k = 1 / (b_k - a^2 v_{k+1}), zero on padded entries
   double vnext = 0.0;
-  for (int k = TS - 1; k >= 0; --k) {
+  for (int k = L - 1; k >= 0; --k) {
     if (k < len) {
       const double vk = 1.0 / (bd[k] - (k < len - 1 ? a * a * vnext : 0.0));
-      tab[T_EV * TS + k] = vk;
-      tab[T_EAV * TS + k] = k < len - 1 ? a * vk : 0.0;
+      tab[T_EV * L + k] = vk;
+      tab[T_EAV * L + k] = k < len - 1 ? a * vk : 0.0;
       vnext = vk;
-      tab[T_EW * TS + k] = tab[T_W * TS + k];
-      tab[T_EAWF * TS + k] = tab[T_AWF * TS + k];
+      tab[T_EW * L + k] = tab[T_W * L + k];
+      tab[T_EAWF * L + k] = tab[T_AWF * L + k];
     } else {
-      tab[T_EW * TS + k] = 0.0;
-      tab[T_EAWF * TS + k] = 1.0;
+      tab[T_EW * L + k] = 0.0;
+      tab[T_EAWF * L + k] = 1.0;
     }
   }
   std::vector<double> g(len, 0.0), h(len, 0.0);
@@ -377,18 +378,22 @@ void build_chunk_table(const DirSpec& s, double a, int p, double* tab, double en
   ends[3] = h[len - 1];
 }
 
+void build_chunk_table(const DirSpec& s, double a, int p, double* tab, double ends[4]) {
+  build_chunk_table_len(s, a, p, TS, tab, ends);
+}
+
 // Reduced-system data of one (field, direction).  `s` describes the GLOBAL line; the local block holds chunks
 // [p0, p0 + Ploc).  Fills icoef[Ploc+1][3] (interface q sits between local chunks q-1 and q; q = 0 / Ploc touch the
 // neighbouring blocks) and, when `lu` is non-NULL (no decomposition: p0 == 0, Ploc == s.P), the banded LU factors
 // [5][2P] (2 sub-, 2 super-diagonals, no pivoting: the matrix is strictly diagonally dominant).  Returns the largest
 // far-coupling weight of the global reduced matrix.
-static double reduced_tables(const DirSpec& s, double a, int p0, int Ploc, double* lu, double* icoef) {
-  std::vector<double> tab(TS * T_NSLOT);
+static double reduced_tables(const DirSpec& s, double a, int p0, int Ploc, double* lu, double* icoef, int L = TS) {
+  std::vector<double> tab(L * T_NSLOT);
   std::vector<double> near_g(s.P), near_h(s.P), far_g(s.P), far_h(s.P);
   double far = 0.0;
   for (int p = 0; p < s.P; ++p) {
     double ends[4];
-    build_chunk_table(s, a, p, tab.data(), ends);
+    build_chunk_table_len(s, a, p, L, tab.data(), ends);
     near_g[p] = a * ends[0];   // weight of E_{p-1} in the F_p equation
     far_g[p] = a * ends[1];    // weight of E_{p-1} in the E_p equation
     far_h[p] = a * ends[2];    // weight of F_{p+1} in the F_p equation
@@ -437,6 +442,8 @@ static double reduced_tables(const DirSpec& s, double a, int p0, int Ploc, doubl
   return far;
 }
 
+#include "qp_adi_fine.inc"
+
 }  // namespace qp
 
 // launches NAME<ARG, STREAM> for the plan's stream mode (0 cached, 2 non-temporal stores, 3 non-temporal both)
@@ -453,8 +460,22 @@ static double reduced_tables(const DirSpec& s, double a, int p0, int Ploc, doubl
     else QP_LAUNCH_STREAMED_C(mode, NAME, ARG, false, __VA_ARGS__);                \
   } while (0)
 
+#define QP_LAUNCH_FINE(mode, NAME, ARG, ...)                                       \
+  do {                                                                             \
+    if ((mode) == 0) hipLaunchKernelGGL((NAME<ARG, 0>), __VA_ARGS__);              \
+    else if ((mode) == 2) hipLaunchKernelGGL((NAME<ARG, 2>), __VA_ARGS__);         \
+    else hipLaunchKernelGGL((NAME<ARG, 3>), __VA_ARGS__);                          \
+  } while (0)
+
 struct qp_adi_rect_plan {
   qp::RectView view;
+  // fine tiles (qp_adi_fine.inc): when `fine`, every pass of this plan runs the 32-cell-chunk kernels on their own
+  // interface arrays (the 64 x 64 view above stays valid for qp_adi_rect_combine and the plan queries)
+  bool fine = false;
+  qp::FineView fview;
+  double* d_fctab = nullptr;
+  double* d_ficoef[2] = {nullptr, nullptr};
+  double* d_fiface[2] = {nullptr, nullptr};
   double* d_alpha = nullptr;
   double* d_tab = nullptr;
   double* d_ctab = nullptr;
@@ -550,6 +571,115 @@ __global__ void __launch_bounds__(256) rect_combine_kernel(int ny, int nx, int n
   }
 }
 
+// Fine tiles are eligible on undecomposed grids whose extents are multiples of 64.  QPSIM_FINE_TILES=0 / 1 forces the
+// choice (1: whenever the plan qualifies); the default is the size rule measured on MI355X.
+static bool fine_tiles_wanted(int nfield, int ny, int nx) {
+  if (ny % 64 != 0 || nx % 64 != 0) return false;
+  if (const char* e = getenv("QPSIM_FINE_TILES")) return atoi(e) != 0;
+  // sweep time in us, 64 x 64 tiles / fine tiles: 1024^2 7.55 / 5.91, 2048^2 15.1 / 13.2, 512^2 x 12 11.8 / 10.2,
+  // 4160 x 2176 28.7 / 25.8, 4096^2 47.0 / 45.9; beyond the cached regime 5760^2 86.9 / 92.7, 8192^2 189 / 187
+  return stream_mode((size_t)nfield * ny * nx * sizeof(double)) == 0;
+}
+
+// Tables, interface coefficients and interface arrays of the fine view; leaves plan->fine false (and no error) when the
+// plan does not qualify: chunks of 32 cells not decoupled at this r D, or a table without the compact form.
+static int fine_plan_create(qp_adi_rect_plan* plan, double r, const double* dcoef_host, const DirSpec (&coarse)[2]) {
+  const RectView& v = plan->view;
+  const int nfield = v.d.nfield, ny = v.d.ny, nx = v.d.nx;
+  FineView& f = plan->fview;
+  f.ny = ny; f.nx = nx; f.nfield = nfield;
+  f.py = ny / FS; f.px = nx / FS;
+  f.stream = v.d.stream;
+  for (int d = 0; d < 2; ++d)
+    for (int k = 0; k < 2; ++k) f.other_src[d][k] = v.other_src[d][k];
+  DirSpec spec[2] = {coarse[0], coarse[1]};
+  spec[0].P = f.px;
+  spec[1].P = f.py;
+  std::vector<double> tab((size_t)T_NSLOT * FS);
+  std::vector<double> ctab((size_t)2 * nfield * 4 * 2 * CT_PART, 0.0);
+  std::vector<double> icoef[2];
+  for (int d = 0; d < 2; ++d) icoef[d].assign((size_t)nfield * (spec[d].P + 1) * 3, 0.0);
+  for (int b = 0; b < nfield; ++b) {
+    const double a = r * dcoef_host[b];
+    for (int d = 0; d < 2; ++d) {
+      const int P = spec[d].P;       // >= 2
+      for (int var = 0; var < 3; ++var) {
+        int p;
+        if (var == 0) { if (P < 3) continue; p = 1; }
+        else if (var == 1) p = 0;
+        else p = P - 1;
+        double ends[4];
+        build_chunk_table_len(spec[d], a, p, FS, tab.data(), ends);
+        {
+          // scaled eliminations (ends32): eawf'_k = eawf_k ew_{k-1} / ew_k, eav'_k = eav_k ev_{k+1} / ev_k; of EW / EV only
+          // the last / first entry is read.  (Full chunks: no padded entries, every pivot is positive.)
+          double* ew = &tab[T_EW * FS]; double* eawf = &tab[T_EAWF * FS];
+          double* ev = &tab[T_EV * FS]; double* eav = &tab[T_EAV * FS];
+          for (int k = FS - 1; k >= 1; --k) eawf[k] = eawf[k] * ew[k - 1] / ew[k];
+          eawf[0] = 0.0;
+          for (int k = 0; k < FS - 1; ++k) eav[k] = eav[k] * ev[k + 1] / ev[k];
+          eav[FS - 1] = 0.0;
+        }
+        if (!table_is_compact_len(FS, tab.data())) return QP_OK;
+        build_compact_table_len(FS, tab.data(), &ctab[(((size_t)d * nfield + b) * 4 + var) * 2 * CT_PART]);
+      }
+      const double far = reduced_tables(spec[d], a, 0, P, nullptr, &icoef[d][(size_t)b * (P + 1) * 3], FS);
+      if (!(far < kFarCouplingDrop)) return QP_OK;
+    }
+  }
+  bool ok = hipMalloc((void**)&plan->d_fctab, ctab.size() * sizeof(double)) == hipSuccess &&
+            hipMemcpy(plan->d_fctab, ctab.data(), ctab.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+  for (int d = 0; d < 2 && ok; ++d) {
+    const size_t nlines = d == 0 ? ny : nx;
+    const size_t ni = (size_t)nfield * (2 * spec[d].P + 2) * nlines;
+    ok = hipMalloc((void**)&plan->d_ficoef[d], icoef[d].size() * sizeof(double)) == hipSuccess &&
+         hipMemcpy(plan->d_ficoef[d], icoef[d].data(), icoef[d].size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMalloc((void**)&plan->d_fiface[d], ni * sizeof(double)) == hipSuccess &&
+         hipMemset(plan->d_fiface[d], 0, ni * sizeof(double)) == hipSuccess;
+  }
+  if (!ok) {
+    (void)hipGetLastError();
+    set_error("qp_adi_rect_plan_create: device allocation or upload failed (fine tiles)");
+    return QP_ERR_ALLOC;
+  }
+  f.alpha = plan->d_alpha;
+  f.ctab = plan->d_fctab;
+  for (int d = 0; d < 2; ++d) {
+    f.icoef[d] = plan->d_ficoef[d];
+    f.iface[d] = plan->d_fiface[d];
+  }
+  plan->fine = true;
+  return QP_OK;
+}
+
+// the passes of qp_adi_rect_phase on the fine view (interfaces always decoupled: the reduced phases are empty)
+static int fine_phase(qp_adi_rect_plan* plan, int phase, double* u, hipStream_t stream) {
+  const FineView& f = plan->fview;
+  const unsigned tiles = (unsigned)((long)f.nfield * (f.ny / 64) * f.px);     // = nfield * py * (nx / 64)
+  double* w = plan->d_work;
+  switch (phase) {
+    case QP_ADI_ENTRY:
+      QP_LAUNCH_FINE(f.stream, fine_y_kernel, 0, dim3(tiles), dim3(64), 0, stream, f, (const double*)u, w);
+      break;
+    case QP_ADI_REDUCED_X:
+    case QP_ADI_REDUCED_Y:
+      break;
+    case QP_ADI_SWEEP_X:
+      QP_LAUNCH_FINE(f.stream, fine_x_kernel, true, dim3(tiles), dim3(64), 0, stream, f, w);
+      break;
+    case QP_ADI_SWEEP_Y_CARRY:
+      QP_LAUNCH_FINE(f.stream, fine_y_kernel, 1, dim3(tiles), dim3(64), 0, stream, f, (const double*)w, w);
+      break;
+    case QP_ADI_SWEEP_Y_EXIT:
+      QP_LAUNCH_FINE(f.stream, fine_y_kernel, 2, dim3(tiles), dim3(64), 0, stream, f, (const double*)w, u);
+      break;
+    default:
+      set_error("qp_adi_rect_phase: unknown phase %d", phase);
+      return QP_ERR_INVALID_ARGUMENT;
+  }
+  return check_launch("qp_adi_rect_phase (fine tiles)");
+}
+
 }  // namespace qp
 
 extern "C" {
@@ -567,6 +697,11 @@ int qp_adi_rect_plan_destroy(qp_adi_rect_plan* plan) {
     (void)hipFree(plan->d_uhalo[d]);
   }
   (void)hipFree(plan->d_work);
+  (void)hipFree(plan->d_fctab);
+  for (int d = 0; d < 2; ++d) {
+    (void)hipFree(plan->d_ficoef[d]);
+    (void)hipFree(plan->d_fiface[d]);
+  }
   delete plan;
   return QP_OK;
 }
@@ -681,6 +816,13 @@ int qp_adi_rect_plan_create_block(int32_t ny, int32_t nx, int32_t nfield, double
     v.z[d] = plan->d_z[d];
     v.uhalo[d] = plan->d_uhalo[d];
   }
+  if (!decomposed && force_banded == 0 && fine_tiles_wanted(nfield, ny, nx)) {
+    const int rc = fine_plan_create(plan, r, dcoef_host, spec);
+    if (rc != QP_OK) {
+      qp_adi_rect_plan_destroy(plan);
+      return rc;
+    }
+  }
   *out = plan;
   return QP_OK;
 }
@@ -696,10 +838,16 @@ int qp_adi_rect_plan_decoupled(const qp_adi_rect_plan* plan, int32_t dir) {
   return plan->view.decoupled[dir];
 }
 
+int qp_adi_rect_plan_fine(const qp_adi_rect_plan* plan) { return plan && plan->fine ? 1 : 0; }
+
 int qp_adi_rect_phase(qp_adi_rect_plan* plan, int32_t phase, double* u, void* stream_) {
   QP_REQUIRE(plan != nullptr, "plan is NULL");
   using namespace qp;
   hipStream_t stream = (hipStream_t)stream_;
+  if (plan->fine) {
+    QP_REQUIRE(u != nullptr || (phase != QP_ADI_ENTRY && phase != QP_ADI_SWEEP_Y_EXIT), "u is NULL");
+    return fine_phase(plan, phase, u, stream);
+  }
   const RectView& v = plan->view;
   const unsigned tiles = (unsigned)((long)v.d.nfield * v.d.py * v.d.px);
   double* w = plan->d_work;
@@ -756,6 +904,14 @@ int qp_adi_rect_solve(qp_adi_rect_plan* plan, double* x, void* stream_) {
   QP_REQUIRE(!plan->decomposed, "qp_adi_rect_solve is not available on decomposed plans");
   using namespace qp;
   hipStream_t stream = (hipStream_t)stream_;
+  if (plan->fine) {
+    const FineView& f = plan->fview;
+    const unsigned ftiles = (unsigned)((long)f.nfield * (f.ny / 64) * f.px);
+    QP_LAUNCH_FINE(f.stream, fine_y_kernel, 3, dim3(ftiles), dim3(64), 0, stream, f, (const double*)x, x);
+    QP_LAUNCH_FINE(f.stream, fine_x_kernel, false, dim3(ftiles), dim3(64), 0, stream, f, x);
+    QP_LAUNCH_FINE(f.stream, fine_y_kernel, 2, dim3(ftiles), dim3(64), 0, stream, f, (const double*)x, x);
+    return check_launch("qp_adi_rect_solve (fine tiles)");
+  }
   const RectView& v = plan->view;
   const unsigned tiles = (unsigned)((long)v.d.nfield * v.d.py * v.d.px);
   QP_LAUNCH_STREAMED(v.d.stream, v.compact, rect_y_kernel, 3, dim3(tiles), dim3(64), 0, stream, v, (const double*)x, x);

@@ -35,39 +35,45 @@ enum { T_W = 0, T_AWF, T_AWB, T_CM, T_C0, T_CP, T_SRC, T_EW, T_EAWF, T_EV, T_EAV
 // every full-length chunk each slot is CONSTANT on [pre, TS - suf): a short prefix / suffix of distinct entries and one
 // value for the middle.  The plan checks that bit for bit per table (`table_is_compact`); kernels then feed the middle of
 // every dependent chain from one SGPR pair and fetch only the prefix / suffix entries.
-constexpr int kTabMid = TS / 2;
+// The same holds for chunks of FS = 32 cells (the fine tiles of qp_adi_fine.inc): the functions take the chunk length L.
+constexpr int FS = 32;
 __host__ __device__ constexpr int slot_pre(int slot) {
   return (slot == T_W || slot == T_AWF || slot == T_AWB || slot == T_EW || slot == T_EAWF) ? 16 : 1;
 }
 __host__ __device__ constexpr int slot_suf(int slot) { return (slot == T_EV || slot == T_EAV) ? 16 : 1; }
-inline bool table_is_compact(const double* tab) {
+// an entry of the constant stretch [pre, L - suf) of a slot
+__host__ __device__ constexpr int slot_mid(int L, int slot) { return (slot == T_EV || slot == T_EAV) ? L - 17 : 16; }
+inline bool table_is_compact_len(int L, const double* tab) {
   for (int q = 0; q < T_NSLOT; ++q)
-    for (int k = slot_pre(q); k < TS - slot_suf(q); ++k)
-      if (tab[q * TS + k] != tab[q * TS + kTabMid]) return false;
+    for (int k = slot_pre(q); k < L - slot_suf(q); ++k)
+      if (tab[q * L + k] != tab[q * L + slot_mid(L, q)]) return false;
   return true;
 }
+inline bool table_is_compact(const double* tab) { return table_is_compact_len(TS, tab); }
 // Compact table = two parts of CT_PART doubles (solve slots T_W..T_SRC, elimination slots T_EW..T_EAV): the 16-entry
 // prefixes / suffixes, then per slot its middle value, its last (or first) entry.  cidx maps (slot, k) into its part.
 constexpr int CT_PART = 72;
-__host__ __device__ constexpr int cidx(int slot, int k) {
+__host__ __device__ constexpr int cidx_len(int L, int slot, int k) {
   if (slot < T_EW) {
     if (slot <= T_AWB && k < 16) return slot * 16 + k;                  // W, AWF, AWB prefixes: 0..47
-    if (k == TS - 1) return 56 + slot;                                  // last entry of every solve slot: 56..62
+    if (k == L - 1) return 56 + slot;                                   // last entry of every solve slot: 56..62
     if (slot >= T_CM && k == 0) return 64 + (slot - T_CM);              // first entry of the explicit slots: 64..67
     return 48 + slot;                                                   // middle: 48..54
   }
   const int q = slot - T_EW;                                            // 0 EW, 1 EAWF, 2 EV, 3 EAV
   if (q < 2 && k < 16) return q * 16 + k;                               // forward prefixes: 0..31
-  if (q >= 2 && k >= TS - 16) return q * 16 + (k - (TS - 16));          // backward suffixes: 32..63
-  if (q < 2 && k == TS - 1) return 68 + q;                              // EW, EAWF last: 68, 69
+  if (q >= 2 && k >= L - 16) return q * 16 + (k - (L - 16));            // backward suffixes: 32..63
+  if (q < 2 && k == L - 1) return 68 + q;                               // EW, EAWF last: 68, 69
   if (q >= 2 && k == 0) return 68 + q;                                  // EV, EAV first: 70, 71
   return 64 + q;                                                        // middle: 64..67
 }
-inline void build_compact_table(const double* tab, double* ct) {       // ct[2][CT_PART]
+__host__ __device__ constexpr int cidx(int slot, int k) { return cidx_len(TS, slot, k); }
+inline void build_compact_table_len(int L, const double* tab, double* ct) {       // ct[2][CT_PART]
   for (int i = 0; i < 2 * CT_PART; ++i) ct[i] = 0.0;
   for (int q = 0; q < T_NSLOT; ++q)
-    for (int k = 0; k < TS; ++k) ct[(q < T_EW ? 0 : CT_PART) + cidx(q, k)] = tab[q * TS + k];
+    for (int k = 0; k < L; ++k) ct[(q < T_EW ? 0 : CT_PART) + cidx_len(L, q, k)] = tab[q * L + k];
 }
+inline void build_compact_table(const double* tab, double* ct) { build_compact_table_len(TS, tab, ct); }
 
 // Tables are written once at plan creation and never by a kernel: read them through the constant address space so
 // that wave-uniform accesses become scalar loads (s_load) and the values feed the FMAs straight from SGPRs.

@@ -226,6 +226,7 @@ class RectPlan:
                                                      int(gny), int(gnx), int(j0), int(i0), C.byref(self._h)),
                    "qp_adi_rect_plan_create_block")
         self.decoupled = (bool(lib.qp_adi_rect_plan_decoupled(self._h, 0)), bool(lib.qp_adi_rect_plan_decoupled(self._h, 1)))
+        self.fine = bool(lib.qp_adi_rect_plan_fine(self._h))      # 32-cell chunks (qp_adi_fine.inc) instead of 64 x 64 tiles
 
     @property
     def handle(self):

@@ -1,0 +1,117 @@
+"""Fine tiles of the rectangle ADI path (32-cell chunks, `csrc/qp_adi_fine.inc`) against the oracle and the 64 x 64 tiles.
+
+The reference path is `qpsim/solver.py:1545-1566` (the scalar diffusion loop) with the operators of `solver.py:174-236`;
+the oracle restates the ADI step (`oracle/qp_oracle.py: ADIStepper`) and the exact CN step (SuperLU).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(float(np.max(np.abs(b))), 1e-300))
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import qp_oracle
+    return qp_oracle
+
+
+def _problem(ny, nx, dx=0.9):
+    from qpsim_amd.engine import Engine, compile_geometry
+    from qpsim_amd.geometry import extract_edge_segments
+    from qpsim_amd.models import BoundaryCondition
+    mask = np.ones((ny, nx), dtype=bool)
+    edges = extract_edge_segments(mask)
+    side_bc = {"left": BoundaryCondition("dirichlet", 0.7), "right": BoundaryCondition("robin", 0.4, 0.2),
+               "up": BoundaryCondition("neumann", -0.3), "down": BoundaryCondition("absorbing")}
+    bcs = {e.edge_id: side_bc[e.normal] for e in edges}
+    return mask, edges, bcs, Engine(compile_geometry(mask, edges, bcs, dx))
+
+
+@pytest.mark.parametrize("ny,nx", [(64, 64), (128, 192), (256, 128), (64, 320), (192, 64)])
+def test_fine_tiles_match_oracle_adi_and_coarse_tiles(O, monkeypatch, ny, nx):
+    """Every pass of the fine kernels (entry, x, carry, exit; first / interior / last chunks in both directions, lines of
+    2 ... 10 chunks) vs the oracle ADI step and vs the 64 x 64 tiles on the same plan parameters."""
+    from qpsim_amd.engine import DiffusionOperator
+    dx, dt = 0.9, 0.11                      # r = 0.0679
+    mask, edges, bcs, eng = _problem(ny, nx, dx)
+    ops = O.build_grid_ops(mask, edges, bcs, dx)
+    Dc = [4.4, 0.35, 0.0, 2.0]              # a = r D up to 0.30: chunks of 32 cells still decouple (far coupling 1.7e-23)
+    rng = np.random.default_rng(ny * 7 + nx)
+    u0 = rng.random((len(Dc), ny * nx))
+    monkeypatch.setenv("QPSIM_FINE_TILES", "1")
+    fine = DiffusionOperator(eng, len(Dc), dt, dcoef=Dc)
+    monkeypatch.setenv("QPSIM_FINE_TILES", "0")
+    coarse = DiffusionOperator(eng, len(Dc), dt, dcoef=Dc)
+    assert fine.rect is not None and fine.rect.fine and not coarse.rect.fine
+    for nsteps in (1, 2, 5):
+        a, b = eng.upload_packed(u0), eng.upload_packed(u0)
+        eng.adi_steps(fine, a, nsteps)
+        eng.adi_steps(coarse, b, nsteps)
+        ha, hb = eng.download_packed(a), eng.download_packed(b)
+        assert rel_err(ha, hb) < 5e-14, nsteps
+        for k, D in enumerate(Dc):
+            st = O.ADIStepper(ops, D, dt)
+            want = u0[k].copy()
+            for _ in range(nsteps):
+                want = st.step(want)
+            assert rel_err(ha[k], want) < 2e-13, (k, nsteps)
+
+
+def test_fine_tiles_are_refused_where_32_cell_chunks_do_not_decouple(monkeypatch):
+    """r D = 0.41: the far coupling of a 32-cell chunk (6.5e-21) is above the 1e-22 drop threshold -> 64 x 64 tiles;
+    extents that are not multiples of 64 and decomposed blocks never get fine tiles."""
+    from qpsim_amd.engine import DiffusionOperator
+    monkeypatch.setenv("QPSIM_FINE_TILES", "1")
+    _, _, _, eng = _problem(128, 128)
+    assert not DiffusionOperator(eng, 2, 0.11, dcoef=[1.0, 6.0]).rect.fine
+    assert DiffusionOperator(eng, 2, 0.11, dcoef=[1.0, 4.0]).rect.fine
+    _, _, _, eng2 = _problem(128, 96)
+    assert not DiffusionOperator(eng2, 1, 0.11, dcoef=[1.0]).rect.fine
+
+
+@pytest.mark.parametrize("ny,nx,D", [(128, 192, 4.0), (64, 64, 1.0)])
+def test_exact_cn_step_with_the_fine_preconditioner_matches_superlu(O, monkeypatch, ny, nx, D):
+    """`qp_adi_rect_solve` on fine tiles (reduce pass, plain x-solve, exit pass) inside the default exact-CN iteration."""
+    from qpsim_amd.engine import DiffusionOperator
+    dx, dt = 0.9, 0.11
+    mask, edges, bcs, eng = _problem(ny, nx, dx)
+    ops = O.build_grid_ops(mask, edges, bcs, dx)
+    monkeypatch.setenv("QPSIM_FINE_TILES", "1")
+    op = DiffusionOperator(eng, 1, dt, dcoef=[D])
+    assert op.rect.fine
+    rng = np.random.default_rng(5)
+    u0 = rng.random((1, ny * nx))
+    a = eng.upload_packed(u0)
+    eng.cn_exact_step(op, a)
+    want = O.CNStepper(ops, D, dt).step(u0[0])
+    assert rel_err(eng.download_packed(a)[0], want) < 1e-11
+
+
+def test_fine_tiles_large_grid_roundtrip_properties(monkeypatch):
+    """2048^2 (65536 fine tiles, both stream-mode-0 kernels): fine vs 64 x 64 tiles on the same field, and conservation of
+    the total under reflective walls."""
+    import torch
+    from qpsim_amd.engine import DiffusionOperator, Engine, compile_geometry
+    from qpsim_amd.geometry import extract_edge_segments
+    from qpsim_amd.models import BoundaryCondition
+    N = 2048
+    mask = np.ones((N, N), dtype=bool)
+    edges = extract_edge_segments(mask)
+    bcs = {e.edge_id: BoundaryCondition("neumann", 0.0) for e in edges}
+    eng = Engine(compile_geometry(mask, edges, bcs, 1.0))
+    monkeypatch.setenv("QPSIM_FINE_TILES", "1")
+    fine = DiffusionOperator(eng, 1, 0.6, dcoef=[1.0])
+    monkeypatch.setenv("QPSIM_FINE_TILES", "0")
+    coarse = DiffusionOperator(eng, 1, 0.6, dcoef=[1.0])
+    assert fine.rect.fine and not coarse.rect.fine
+    g = torch.Generator(device="cpu").manual_seed(3)
+    u0 = torch.rand(1, N * N, generator=g, dtype=torch.float64).cuda()
+    a, b = u0.clone(), u0.clone()
+    eng.adi_steps(fine, a, 7)
+    eng.adi_steps(coarse, b, 7)
+    assert float((a - b).abs().max() / b.abs().max()) < 5e-14
+    assert abs(float(a.sum() / u0.sum()) - 1.0) < 1e-12
