@@ -58,7 +58,8 @@ class ADIWorkload:
         self.grid = [N, N]
         self.cell_updates_per_step = float(ncell) * nfield          # cells inside the mask only
         self.bytes_per_step = 32.0 * self.cell_updates_per_step     # 2 sweeps x (8 B read + 8 B write)
-        self.path = ("rect-tiled partition ADI" if self.op.rect is not None else
+        self.path = ("rect-tiled partition ADI, fine tiles (32-cell chunks)" if self.op.rect is not None and self.op.rect.fine else
+                     "rect-tiled partition ADI" if self.op.rect is not None else
                      f"masked tiled ADI {self.op.tile.tile_counts}" if self.op.tile is not None else "general per-line Thomas")
         shape = "ring mask (donut)" if ring else "full rectangle"
         self.description = (f"{N}x{N} fp64 CN-ADI step (Peaceman-Rachford, both sweeps), {nfield} field(s), "
@@ -84,7 +85,9 @@ class ADIWorkload:
             return None
         k = json.loads((prof / name).read_text())["kernels"]
         pick = lambda frag: sum(v["hbm_bytes_per_launch"] for n_, v in k.items() if frag in n_)  # noqa: E731
-        if self.op.rect is not None:
+        if self.op.rect is not None and self.op.rect.fine:
+            val = 0.5 * (pick("fine_x_kernel<true, 0>") + pick("fine_y_kernel<1, 0>"))
+        elif self.op.rect is not None:
             val = 0.5 * (pick("rect_x_kernel<true, 0, true>") + pick("rect_y_kernel<1, 0, true>"))
         elif self.op.tile is not None:      # one sweep = one merged launch (clean + general tiles); mean of x and carried y
             val = 0.5 * (pick("tile_x_merged_kernel<true>") + pick("tile_y_merged_kernel<1>"))
@@ -116,7 +119,9 @@ class ADIWorkload:
                 "traffic_source": None if traffic is None else
                 "profiles/r02_*_pmc.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not measured "
                 "in this run)",
-                "kernel": ("rect_x_kernel / rect_y_kernel (one tile sweep)" if self.op.rect is not None else
+                "kernel": ("fine_x_kernel / fine_y_kernel (one tile sweep, 32-cell chunks)"
+                           if self.op.rect is not None and self.op.rect.fine else
+                           "rect_x_kernel / rect_y_kernel (one tile sweep)" if self.op.rect is not None else
                            "tile_x_kernel / tile_y_kernel, clean + general launches of one sweep" if self.op.tile is not None
                            else "thomas_lines_kernel"),
                 "bytes_per_launch": bytes_per_launch, "avg_launch_us": per_sweep_s * 1e6,
@@ -440,7 +445,9 @@ class OverlapDecomposedWorkload:
         bytes_per_launch = 16.0 * self.block.ey * self.block.ex
         achieved = bytes_per_launch / per_sweep / 1e9
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "kernel": "rect_x_kernel / rect_y_kernel on the extended local block (rank 0)",
+                "traffic": None,
+                "kernel": ("fine_x_kernel / fine_y_kernel" if self.block.plan.fine else "rect_x_kernel / rect_y_kernel")
+                + " on the extended local block (rank 0)",
                 "bytes_per_launch": bytes_per_launch, "avg_launch_us": per_sweep * 1e6,
                 "note": "per-rank sweep on block + halos; the halo cells are redundant work and are NOT counted in `value`"}
 
