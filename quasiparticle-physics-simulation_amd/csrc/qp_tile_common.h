@@ -197,6 +197,19 @@ constexpr int HB = 32;
 constexpr int HP = HB + 1;
 constexpr int LDS_DOUBLES = 2 * HB * HP;
 
+// The workgroup of every tile kernel is ONE wave (they are launched with 64 threads) and a wave's LDS instructions execute in order, so
+// no s_barrier is needed between the writes and the reads of a patch - only a fence that keeps the compiler from moving
+// LDS accesses across it.
+__device__ __forceinline__ void wave_lds_fence() {
+#ifdef QP_TILE_BARRIERS
+  __syncthreads();
+#else
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
 __device__ __forceinline__ void swap_half_waves(double& lo_reg, double& hi_reg) {
   // lanes 32..63 of lo_reg <-> lanes 0..31 of hi_reg
   const unsigned long long a = __double_as_longlong(lo_reg), b = __double_as_longlong(hi_reg);
@@ -216,10 +229,10 @@ __device__ __forceinline__ void transpose64(double (&v)[TS], double* lds, int la
   for (int half = 0; half < 2; ++half) {
 #pragma unroll
     for (int k = 0; k < HB; ++k) blk[k * HP + l] = v[half * HB + k];
-    __syncthreads();
+    wave_lds_fence();
 #pragma unroll
     for (int k = 0; k < HB; ++k) v[half * HB + k] = blk[l * HP + k];
-    __syncthreads();
+    wave_lds_fence();
   }
 }
 
