@@ -78,9 +78,9 @@ class ADIWorkload:
         import json
         from pathlib import Path
         prof = Path(__file__).resolve().parents[2] / "profiles"
-        if self.N != 4096 or self.nfield != 1:
+        if self.nfield != 1 or self.N not in ((4096,) if self.ring else (1024, 2048, 4096)):
             return None
-        name = "r02_ring4096_pmc.json" if self.ring else "r02_adi4096_pmc.json"
+        name = "r02_ring4096_pmc.json" if self.ring else f"r02_adi{self.N}_pmc.json"
         if not (prof / name).exists():
             return None
         k = json.loads((prof / name).read_text())["kernels"]

@@ -27,5 +27,7 @@ stats c2 "--workload c2 --steps 30 --warmup 5"
 stats adi8192 "--workload adi8192 --steps 20 --warmup 3"
 stats adi2048 "--workload adi2048 --steps 200 --warmup 20"
 stats adi1024 "--workload adi1024 --steps 400 --warmup 40"
+traffic adi1024 "--workload adi1024 --steps 100 --warmup 10"
+traffic adi2048 "--workload adi2048 --steps 50 --warmup 5"
 stats coupled1024ne50 "--workload coupled1024ne50 --steps 6 --warmup 2"
 cd $R && cat $out/*_pmc.txt | cut -c1-170
