@@ -253,6 +253,19 @@ int qp_adi_rect_plan_decoupled(const qp_adi_rect_plan* plan, int32_t dir);
  * undecomposed grids whose extents are multiples of 64, r*D <~ 0.32 for every field, size rule or QPSIM_FINE_TILES=1),
  * 0 for the 64 x 64 tiles.  Same results to rounding (the dropped far couplings are < 1e-22 either way). */
 int qp_adi_rect_plan_fine(const qp_adi_rect_plan* plan);
+/* Peaceman-Rachford iteration for the UNSPLIT Crank-Nicolson system A u = b, A = I - r D (Lx + Ly) (the matrix the
+ * reference factorises with SuperLU, solver.py:231,1155-1161), on full rectangles whose Lx and Ly commute:
+ *   (H + p) u* = b - (V - p) u,   (V + p) u' = b - (H - p) u*,     H = I/2 - r D Lx,  V = I/2 - r D Ly.
+ * qp_adi_rect_plan_create_pr builds the plan of ONE parameter p > 0 (tables of the sweeps with r D / (1/2 + p), explicit
+ * operators with the shifted diagonal; boundary sources belong to b).  Requires fine tiles (QP_ERR_UNSUPPORTED otherwise:
+ * extents multiples of 64, r D / (1/2 + p) <~ 0.32).  `share` (may be NULL): another plan of the same shape whose work
+ * plane is borrowed - a cycle of J parameters then holds one work plane, not J; destroy the lender last.
+ * qp_adi_rect_pr_iteration overwrites u with the next iterate (three passes: 8 B read + 8 B read of b + 8 B written,
+ * twice, and 8 + 8 B for the last solve, per cell).  With parameters spread over the spectrum of H and V, [1/2, 1/2 +
+ * r D (4 + boundary term)], J = 5-7 iterations reduce the error by 1e-13 (the host chooses them: qpsim_amd/engine.py). */
+int qp_adi_rect_plan_create_pr(int32_t ny, int32_t nx, int32_t nfield, double r, const double* dcoef_host,
+                               const double* bc_diag, double p, qp_adi_rect_plan* share, qp_adi_rect_plan** out);
+int qp_adi_rect_pr_iteration(qp_adi_rect_plan* plan, double* u, const double* b, void* stream);
 int qp_adi_rect_steps(qp_adi_rect_plan* plan, double* u, int32_t nsteps, void* stream);
 /* qp_stencil_combine for the plan's operator without per-cell geometry arrays (positions decide which side term applies):
  * out = c0 u + cx (a Lx u) + cy (a Ly u) + cs a S + cr rin on [nfield][ny*nx]; with norm_out non-NULL also

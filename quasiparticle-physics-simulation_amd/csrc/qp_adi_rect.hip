@@ -467,6 +467,13 @@ static double reduced_tables(const DirSpec& s, double a, int p0, int Ploc, doubl
     else hipLaunchKernelGGL((NAME<ARG, 3>), __VA_ARGS__);                          \
   } while (0)
 
+#define QP_LAUNCH_FINE_SRC(mode, NAME, ARG, ...)                                   \
+  do {                                                                             \
+    if ((mode) == 0) hipLaunchKernelGGL((NAME<ARG, 0, true>), __VA_ARGS__);        \
+    else if ((mode) == 2) hipLaunchKernelGGL((NAME<ARG, 2, true>), __VA_ARGS__);   \
+    else hipLaunchKernelGGL((NAME<ARG, 3, true>), __VA_ARGS__);                    \
+  } while (0)
+
 struct qp_adi_rect_plan {
   qp::RectView view;
   // fine tiles (qp_adi_fine.inc): when `fine`, every pass of this plan runs the 32-cell-chunk kernels on their own
@@ -485,6 +492,8 @@ struct qp_adi_rect_plan {
   double* d_z[2] = {nullptr, nullptr};
   double* d_uhalo[2] = {nullptr, nullptr};
   double* d_work = nullptr;  // [nfield][ncell] carried right-hand side
+  bool owns_work = true;     // false: d_work belongs to another plan (qp_adi_rect_plan_create_pr with `share`)
+  double pr_scale = 0.0;     // != 0: Peaceman-Rachford iteration plan, 1 / (1/2 + p)
   long ncell = 0;
   bool decomposed = false;
   double bc_diag[4] = {0, 0, 0, 0};   // left, right, up, down (1/dx^2 units)
@@ -583,7 +592,8 @@ static bool fine_tiles_wanted(int nfield, int ny, int nx) {
 
 // Tables, interface coefficients and interface arrays of the fine view; leaves plan->fine false (and no error) when the
 // plan does not qualify: chunks of 32 cells not decoupled at this r D, or a table without the compact form.
-static int fine_plan_create(qp_adi_rect_plan* plan, double r, const double* dcoef_host, const DirSpec (&coarse)[2]) {
+static int fine_plan_create(qp_adi_rect_plan* plan, double r, const double* dcoef_host, const DirSpec (&coarse)[2],
+                            double c0_shift = 0.0) {
   const RectView& v = plan->view;
   const int nfield = v.d.nfield, ny = v.d.ny, nx = v.d.nx;
   FineView& f = plan->fview;
@@ -619,6 +629,8 @@ static int fine_plan_create(qp_adi_rect_plan* plan, double r, const double* dcoe
           eawf[0] = 0.0;
           for (int k = 0; k < FS - 1; ++k) eav[k] = eav[k] * ev[k + 1] / ev[k];
           eav[FS - 1] = 0.0;
+          // Peaceman-Rachford iteration plans: the explicit operator is (I + a L) - c0_shift I
+          for (int k = 0; k < FS; ++k) tab[T_C0 * FS + k] -= c0_shift;
         }
         if (!table_is_compact_len(FS, tab.data())) return QP_OK;
         build_compact_table_len(FS, tab.data(), &ctab[(((size_t)d * nfield + b) * 4 + var) * 2 * CT_PART]);
@@ -643,6 +655,8 @@ static int fine_plan_create(qp_adi_rect_plan* plan, double r, const double* dcoe
     return QP_ERR_ALLOC;
   }
   f.alpha = plan->d_alpha;
+  f.bsrc = nullptr;
+  f.bscale = 0.0;
   f.ctab = plan->d_fctab;
   for (int d = 0; d < 2; ++d) {
     f.icoef[d] = plan->d_ficoef[d];
@@ -696,7 +710,7 @@ int qp_adi_rect_plan_destroy(qp_adi_rect_plan* plan) {
     (void)hipFree(plan->d_z[d]);
     (void)hipFree(plan->d_uhalo[d]);
   }
-  (void)hipFree(plan->d_work);
+  if (plan->owns_work) (void)hipFree(plan->d_work);
   (void)hipFree(plan->d_fctab);
   for (int d = 0; d < 2; ++d) {
     (void)hipFree(plan->d_ficoef[d]);
@@ -706,9 +720,12 @@ int qp_adi_rect_plan_destroy(qp_adi_rect_plan* plan) {
   return QP_OK;
 }
 
-int qp_adi_rect_plan_create_block(int32_t ny, int32_t nx, int32_t nfield, double r, const double* dcoef_host,
-                                  const double* bc_diag, const double* bc_src, int32_t force_banded, int32_t gny,
-                                  int32_t gnx, int32_t j0, int32_t i0, qp_adi_rect_plan** out) {
+// pr_scale != 0: plan of one Peaceman-Rachford iteration (qp_adi_rect_plan_create_pr) - fine tiles are mandatory, the
+// 64 x 64 view gets no interface arrays, the carried plane may be borrowed from `share`.
+static int rect_plan_create_impl(int32_t ny, int32_t nx, int32_t nfield, double r, const double* dcoef_host,
+                                 const double* bc_diag, const double* bc_src, int32_t force_banded, int32_t gny,
+                                 int32_t gnx, int32_t j0, int32_t i0, double pr_scale, qp_adi_rect_plan* share,
+                                 qp_adi_rect_plan** out) {
   QP_REQUIRE(out != nullptr, "out is NULL");
   *out = nullptr;
   QP_REQUIRE(ny > 0 && nx > 0 && nfield > 0, "ny, nx, nfield must be positive");
@@ -795,11 +812,18 @@ int qp_adi_rect_plan_create_block(int32_t ny, int32_t nx, int32_t nfield, double
   if (const char* e = getenv("QPSIM_COMPACT_TABLES")) v.compact = v.compact && atoi(e) != 0;   // 0: force the full form
   for (int d = 0; d < 2 && ok; ++d) {
     const size_t nlines = d == 0 ? ny : nx;
+    const bool lean = pr_scale != 0.0;       // the 64 x 64 kernels never run on such a plan
     ok = upload(lu[d], &plan->d_lu[d]) && upload(icoef[d], &plan->d_icoef[d]) &&
-         zalloc(&plan->d_iface[d], (size_t)nfield * (2 * ploc[d] + 2) * nlines) &&
-         zalloc(&plan->d_z[d], (size_t)nfield * 2 * ploc[d] * nlines) && zalloc(&plan->d_uhalo[d], (size_t)nfield * nx);
+         zalloc(&plan->d_iface[d], lean ? 1 : (size_t)nfield * (2 * ploc[d] + 2) * nlines) &&
+         zalloc(&plan->d_z[d], lean ? 1 : (size_t)nfield * 2 * ploc[d] * nlines) &&
+         zalloc(&plan->d_uhalo[d], lean ? 1 : (size_t)nfield * nx);
   }
-  ok = ok && hipMalloc((void**)&plan->d_work, (size_t)nfield * plan->ncell * sizeof(double)) == hipSuccess;
+  if (share) {
+    plan->d_work = share->d_work;
+    plan->owns_work = false;
+  } else {
+    ok = ok && hipMalloc((void**)&plan->d_work, (size_t)nfield * plan->ncell * sizeof(double)) == hipSuccess;
+  }
   if (!ok) {
     (void)hipGetLastError();
     qp_adi_rect_plan_destroy(plan);
@@ -816,15 +840,63 @@ int qp_adi_rect_plan_create_block(int32_t ny, int32_t nx, int32_t nfield, double
     v.z[d] = plan->d_z[d];
     v.uhalo[d] = plan->d_uhalo[d];
   }
-  if (!decomposed && force_banded == 0 && fine_tiles_wanted(nfield, ny, nx)) {
-    const int rc = fine_plan_create(plan, r, dcoef_host, spec);
+  plan->pr_scale = pr_scale;
+  if (!decomposed && force_banded == 0 && ny % 64 == 0 && nx % 64 == 0 &&
+      (pr_scale != 0.0 || fine_tiles_wanted(nfield, ny, nx))) {
+    const int rc = fine_plan_create(plan, r, dcoef_host, spec, pr_scale);
     if (rc != QP_OK) {
       qp_adi_rect_plan_destroy(plan);
       return rc;
     }
   }
+  if (pr_scale != 0.0 && !plan->fine) {
+    qp_adi_rect_plan_destroy(plan);
+    set_error("qp_adi_rect_plan_create_pr: the grid does not qualify for fine tiles (extents multiples of 64, r D / (1/2 + p) "
+              "<~ 0.32 for every field)");
+    return QP_ERR_UNSUPPORTED;
+  }
   *out = plan;
   return QP_OK;
+}
+
+int qp_adi_rect_plan_create_block(int32_t ny, int32_t nx, int32_t nfield, double r, const double* dcoef_host,
+                                  const double* bc_diag, const double* bc_src, int32_t force_banded, int32_t gny,
+                                  int32_t gnx, int32_t j0, int32_t i0, qp_adi_rect_plan** out) {
+  return rect_plan_create_impl(ny, nx, nfield, r, dcoef_host, bc_diag, bc_src, force_banded, gny, gnx, j0, i0, 0.0, nullptr,
+                               out);
+}
+
+// Plan of ONE Peaceman-Rachford iteration with parameter p > 0 for the unsplit Crank-Nicolson system
+//   A u = b,  A = I - a (Lx + Ly) = H + V,  H = I/2 - a Lx,  V = I/2 - a Ly   (a = r D per field):
+//   (H + p) u* = b - (V - p) u,   (V + p) u' = b - (H - p) u*.
+// Divided by 1/2 + p =: 1/s these are the sweeps of an ADI step with a' = s a whose explicit operators are
+// (I + a' L) - s I and whose right-hand sides receive s b: the plan holds the tables of a' with the shifted diagonal
+// (boundary SOURCES belong to b, the plan has none); qp_adi_rect_pr_iteration runs the three passes.
+int qp_adi_rect_plan_create_pr(int32_t ny, int32_t nx, int32_t nfield, double r, const double* dcoef_host,
+                               const double* bc_diag, double p, qp_adi_rect_plan* share, qp_adi_rect_plan** out) {
+  QP_REQUIRE(p > 0.0, "the iteration parameter must be positive");
+  QP_REQUIRE(!share || (share->ncell == (long)ny * nx && share->view.d.nfield == nfield),
+             "the plan whose work plane is shared must have the same shape");
+  const double s = 1.0 / (0.5 + p);
+  const double zero[4] = {0.0, 0.0, 0.0, 0.0};
+  return rect_plan_create_impl(ny, nx, nfield, r * s, dcoef_host, bc_diag, zero, 0, ny, nx, 0, 0, s, share, out);
+}
+
+// u <- one Peaceman-Rachford iteration towards A u = b (see qp_adi_rect_plan_create_pr), u and b [nfield][ny*nx].
+int qp_adi_rect_pr_iteration(qp_adi_rect_plan* plan, double* u, const double* b, void* stream_) {
+  QP_REQUIRE(plan && u && b, "plan, u, b must be non-NULL");
+  QP_REQUIRE(plan->pr_scale != 0.0 && plan->fine, "not a Peaceman-Rachford plan (qp_adi_rect_plan_create_pr)");
+  using namespace qp;
+  hipStream_t stream = (hipStream_t)stream_;
+  FineView f = plan->fview;
+  f.bsrc = b;
+  f.bscale = plan->pr_scale;
+  const unsigned tiles = (unsigned)((long)f.nfield * (f.ny / 64) * f.px);
+  double* w = plan->d_work;
+  QP_LAUNCH_FINE_SRC(f.stream, fine_y_kernel, 0, dim3(tiles), dim3(64), 0, stream, f, (const double*)u, w);
+  QP_LAUNCH_FINE_SRC(f.stream, fine_x_kernel, true, dim3(tiles), dim3(64), 0, stream, f, w);
+  QP_LAUNCH_FINE(f.stream, fine_y_kernel, 2, dim3(tiles), dim3(64), 0, stream, f, (const double*)w, u);
+  return check_launch("qp_adi_rect_pr_iteration");
 }
 
 int qp_adi_rect_plan_create(int32_t ny, int32_t nx, int32_t nfield, double r, const double* dcoef_host,

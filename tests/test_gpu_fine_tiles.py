@@ -74,21 +74,53 @@ def test_fine_tiles_are_refused_where_32_cell_chunks_do_not_decouple(monkeypatch
 
 
 @pytest.mark.parametrize("ny,nx,D", [(128, 192, 4.0), (64, 64, 1.0)])
-def test_exact_cn_step_with_the_fine_preconditioner_matches_superlu(O, monkeypatch, ny, nx, D):
-    """`qp_adi_rect_solve` on fine tiles (reduce pass, plain x-solve, exit pass) inside the default exact-CN iteration."""
-    from qpsim_amd.engine import DiffusionOperator
+@pytest.mark.parametrize("pr", ["1", "0"])
+def test_exact_cn_step_on_fine_tiles_matches_superlu(O, monkeypatch, ny, nx, D, pr):
+    """Default (unsplit CN) step vs the oracle's SuperLU solve (`solver.py:231,1155-1161`), Dirichlet / Robin / Neumann /
+    absorbing sides: pr = 1 the Peaceman-Rachford cycle (`qp_adi_rect_pr_iteration`, source-plane passes of the fine
+    kernels), pr = 0 the ADI-preconditioned Chebyshev iteration whose preconditioner runs `qp_adi_rect_solve` on fine tiles
+    (reduce pass, plain x-solve, exit pass)."""
+    from qpsim_amd.engine import DiffusionOperator, _pr_cycle
     dx, dt = 0.9, 0.11
     mask, edges, bcs, eng = _problem(ny, nx, dx)
     ops = O.build_grid_ops(mask, edges, bcs, dx)
     monkeypatch.setenv("QPSIM_FINE_TILES", "1")
-    op = DiffusionOperator(eng, 1, dt, dcoef=[D])
+    monkeypatch.setenv("QPSIM_CN_PR", pr)
+    nf = 3
+    Dc = [D, 0.3 * D, 0.0]
+    op = DiffusionOperator(eng, nf, dt, dcoef=Dc)
     assert op.rect.fine
+    cycle = _pr_cycle(op, 1e-11)
+    assert (cycle is not None) == (pr == "1")
     rng = np.random.default_rng(5)
-    u0 = rng.random((1, ny * nx))
+    u0 = rng.random((nf, ny * nx))
     a = eng.upload_packed(u0)
-    eng.cn_exact_step(op, a)
-    want = O.CNStepper(ops, D, dt).step(u0[0])
+    its = eng.cn_exact_step(op, a)      # rough data + boundary sources: the first cycle may need polishing (count returned)
+    assert its >= 1
+    got = eng.download_packed(a)
+    for k, Dk in enumerate(Dc):
+        want = O.CNStepper(ops, Dk, dt).step(u0[k])
+        assert rel_err(got[k], want) < 1e-11, k
+    # several steps: the cycle length adapts to the (now smoother) data and the result stays on the reference
+    counts = [eng.cn_exact_step(op, a) for _ in range(4)]
+    if pr == "1":       # the cycle length has adapted: the last steps are served by one cycle alone
+        assert counts[-1] == len(_pr_cycle(op, getattr(op, "_pr_target", 1e-11))) and 4 <= counts[-1] <= 12, counts
+    want = u0[0].copy()
+    st = O.CNStepper(ops, Dc[0], dt)
+    for _ in range(5):
+        want = st.step(want)
     assert rel_err(eng.download_packed(a)[0], want) < 1e-11
+
+
+def test_peaceman_rachford_cycle_is_refused_where_it_does_not_apply(monkeypatch):
+    """Stiff step (r D / (1/2 + p) above the fine-tile limit), a negative boundary diagonal term, extents that are not
+    multiples of 64: no cycle, the step runs the preconditioned iteration."""
+    from qpsim_amd.engine import DiffusionOperator, _pr_cycle
+    _, _, _, eng = _problem(128, 128)
+    assert _pr_cycle(DiffusionOperator(eng, 1, 0.11, dcoef=[1.0]), 1e-11) is not None
+    assert _pr_cycle(DiffusionOperator(eng, 1, 0.11, dcoef=[40.0]), 1e-11) is None
+    _, _, _, eng2 = _problem(128, 100)
+    assert _pr_cycle(DiffusionOperator(eng2, 1, 0.11, dcoef=[1.0]), 1e-11) is None
 
 
 def test_fine_tiles_large_grid_roundtrip_properties(monkeypatch):
@@ -115,3 +147,49 @@ def test_fine_tiles_large_grid_roundtrip_properties(monkeypatch):
     eng.adi_steps(coarse, b, 7)
     assert float((a - b).abs().max() / b.abs().max()) < 5e-14
     assert abs(float(a.sum() / u0.sum()) - 1.0) < 1e-12
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fine_tiles_fuzz_against_coarse_tiles_and_general_kernels(monkeypatch, seed):
+    """Random extents (multiples of 64), boundary kinds / values per side, diffusivities and step counts: the fine tiles,
+    the 64 x 64 tiles and the per-line general kernels (a different algorithm: one Thomas solve per grid line) agree."""
+    from qpsim_amd.engine import DiffusionOperator, Engine, compile_geometry
+    from qpsim_amd.geometry import extract_edge_segments
+    from qpsim_amd.models import BoundaryCondition
+    rng = np.random.default_rng(1000 + seed)
+    ny, nx = (int(64 * rng.integers(1, 6)) for _ in range(2))
+    mask = np.ones((ny, nx), dtype=bool)
+    edges = extract_edge_segments(mask)
+
+    def bc():
+        kind = ["dirichlet", "neumann", "robin", "absorbing", "reflective"][int(rng.integers(0, 5))]
+        if kind == "robin":
+            return BoundaryCondition("robin", float(rng.uniform(-0.5, 0.5)), float(rng.uniform(0.05, 1.0)))
+        if kind in ("dirichlet", "neumann"):
+            return BoundaryCondition(kind, float(rng.uniform(-0.5, 0.9)))
+        return BoundaryCondition(kind)
+
+    side_bc = {side: bc() for side in ("left", "right", "up", "down")}
+    bcs = {e.edge_id: side_bc[e.normal] for e in edges}
+    dx, dt = float(rng.uniform(0.7, 1.3)), float(rng.uniform(0.05, 0.15))
+    r = 0.5 * dt / dx ** 2
+    nf = int(rng.integers(1, 5))
+    Dc = [float(v) for v in rng.uniform(0.0, 0.31 / r, nf)]          # r D < 0.31: fine tiles qualify
+    if seed % 3 == 0:
+        Dc[0] = 0.0
+    eng = Engine(compile_geometry(mask, edges, bcs, dx))
+    monkeypatch.setenv("QPSIM_FINE_TILES", "1")
+    fine = DiffusionOperator(eng, nf, dt, dcoef=Dc)
+    monkeypatch.setenv("QPSIM_FINE_TILES", "0")
+    coarse = DiffusionOperator(eng, nf, dt, dcoef=Dc)
+    slow = DiffusionOperator(eng, nf, dt, dcoef=Dc, allow_fast=False)
+    assert fine.rect.fine and not coarse.rect.fine and slow.rect is None
+    u0 = rng.random((nf, ny * nx))
+    nsteps = int(rng.integers(1, 7))
+    a, b, c = (eng.upload_packed(u0) for _ in range(3))
+    eng.adi_steps(fine, a, nsteps)
+    eng.adi_steps(coarse, b, nsteps)
+    eng.adi_steps(slow, c, nsteps)
+    ha, hb, hc = (eng.download_packed(t) for t in (a, b, c))
+    assert rel_err(ha, hb) < 5e-14, (ny, nx, side_bc, Dc, nsteps)
+    assert rel_err(ha, hc) < 5e-13, (ny, nx, side_bc, Dc, nsteps)

@@ -194,3 +194,37 @@ def test_merged_bin_tagging_pairs_each_shared_bin_once():
         tags_a = {int(v & 0xffff): int(v >> 16) for v in ta if v >> 16}
         assert tags_d == tags_a and sorted(tags_d) == shared and sorted(tags_d.values()) == list(range(1, n + 1))
         assert td[0] >> 16 == 0
+
+
+def test_peaceman_rachford_parameters_meet_their_bound_on_a_commuting_model_problem():
+    """`engine.peaceman_rachford_parameters`: the cycle's worst-case factor on [alpha, beta] is what it says, and a cycle
+    applied to an actual commuting pair H, V (1-D Laplacians with mixed boundary terms, tensor structure as on a full
+    rectangle) reduces the error of A u = b, A = H + V, by at least that factor."""
+    from qpsim_amd.engine import peaceman_rachford_parameters
+    a = 0.3
+    for reduction in (1e-6, 1e-11):
+        ps, worst = peaceman_rachford_parameters(0.5, 0.5 + 4.0 * a, reduction)
+        assert worst <= reduction and 2 <= len(ps) <= 12
+        shorter, w2 = peaceman_rachford_parameters(0.5, 0.5 + 4.0 * a, reduction, jmax=len(ps) - 1)
+        assert w2 > reduction      # the returned J is the smallest that meets the bound
+
+    def lap(n, e_lo, e_hi):
+        L = -2.0 * np.eye(n) + np.eye(n, k=1) + np.eye(n, k=-1)
+        L[0, 0] = -(1.0 + e_lo)
+        L[-1, -1] = -(1.0 + e_hi)
+        return L
+
+    nx, ny = 24, 17
+    Hx = 0.5 * np.eye(nx) - a * lap(nx, 0.0, 2.0)
+    Vy = 0.5 * np.eye(ny) - a * lap(ny, 0.4, 0.0)
+    H, V = np.kron(np.eye(ny), Hx), np.kron(Vy, np.eye(nx))
+    rng = np.random.default_rng(0)
+    x = rng.random(nx * ny)
+    b = (H + V) @ x
+    ps, worst = peaceman_rachford_parameters(0.5, 0.5 + a * 4.0, 1e-9)
+    u = np.zeros_like(x)
+    I = np.eye(nx * ny)
+    for p in ps:
+        us = np.linalg.solve(H + p * I, b - (V - p * I) @ u)
+        u = np.linalg.solve(V + p * I, b - (H - p * I) @ us)
+    assert np.linalg.norm(u - x) <= 1.01 * worst * np.linalg.norm(x)
