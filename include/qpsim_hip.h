@@ -257,8 +257,9 @@ int qp_adi_rect_plan_fine(const qp_adi_rect_plan* plan);
  * reference factorises with SuperLU, solver.py:231,1155-1161), on full rectangles whose Lx and Ly commute:
  *   (H + p) u* = b - (V - p) u,   (V + p) u' = b - (H - p) u*,     H = I/2 - r D Lx,  V = I/2 - r D Ly.
  * qp_adi_rect_plan_create_pr builds the plan of ONE parameter p > 0 (tables of the sweeps with r D / (1/2 + p), explicit
- * operators with the shifted diagonal; boundary sources belong to b).  Requires fine tiles (QP_ERR_UNSUPPORTED otherwise:
- * extents multiples of 64, r D / (1/2 + p) <~ 0.32).  `share` (may be NULL): another plan of the same shape whose work
+ * operators with the shifted diagonal; boundary sources belong to b); it runs the fine tiles where the grid qualifies
+ * (extents multiples of 64, r D / (1/2 + p) <~ 0.32) and the 64 x 64 tiles - any extents, banded reduced systems for
+ * stiff steps - elsewhere.  `share` (may be NULL): another plan of the same shape whose work
  * plane is borrowed - a cycle of J parameters then holds one work plane, not J; destroy the lender last.
  * qp_adi_rect_pr_iteration overwrites u with the next iterate (three passes: 8 B read + 8 B read of b + 8 B written,
  * twice, and 8 + 8 B for the last solve, per cell).  With parameters spread over the spectrum of H and V, [1/2, 1/2 +

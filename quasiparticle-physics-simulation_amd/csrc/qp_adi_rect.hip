@@ -59,6 +59,9 @@ struct RectView {
   const double* uhalo[2];       // [nfield][nx]: field row just above / below the local block (entry pass, decomposed)
   int decoupled[2];             // per dir: far couplings underflow -> every interface is an independent 2 x 2 system
   double other_src[2][2];       // [dir][lo/hi]: a-less source of the faces normal to `dir` (x: sx_lo, sx_hi)
+  // Peaceman-Rachford iteration passes (<..., SRC = true>): bscale * bsrc is added to every right-hand side formed
+  const double* bsrc;           // [nfield][ny*nx]
+  double bscale;
 };
 
 // coefficient source of one kernel phase: the full table of (dir, field, variant) in registers, or a part of its compact form
@@ -171,7 +174,7 @@ __device__ __forceinline__ void ghost_finish(const RectView& v, int b, int p, bo
 #define QP_WAVES_ATTR
 #endif
 
-template <bool EXPLICIT, int STREAM, bool COMPACT>
+template <bool EXPLICIT, int STREAM, bool COMPACT, bool SRC = false>
 __global__ void __launch_bounds__(64) QP_WAVES_ATTR rect_x_kernel(RectView v, double* __restrict__ buf) {
   __shared__ double lds[LDS_DOUBLES];
   const int lane = threadIdx.x;
@@ -201,6 +204,7 @@ __global__ void __launch_bounds__(64) QP_WAVES_ATTR rect_x_kernel(RectView v, do
   if (EXPLICIT) explicit64(e, gl, gr, cx, row_on ? srow : 0.0);
   transpose64(e, lds, lane);
   // lane = column again
+  if (SRC) add_source_cols(v.bsrc + (long)t.b * ncell, t, v.d.nx, lane, v.bscale, e);
   store_cols(plane, t, v.d.nx, lane, e);
   if (QP_ABL & 8) return;
   double yf, yl;
@@ -218,7 +222,7 @@ __global__ void __launch_bounds__(64) QP_WAVES_ATTR rect_x_kernel(RectView v, do
 //            MODE 2 (exit):  src = rhs2, y-solve, dst = u'
 //            MODE 3 (reduce): src = rhs of an x-solve; only its reduced right-hand sides are formed (nothing stored)
 // ---------------------------------------------------------------------------------------------------------
-template <int MODE, int STREAM, bool COMPACT>
+template <int MODE, int STREAM, bool COMPACT, bool SRC = false>
 __global__ void __launch_bounds__(64) QP_WAVES_ATTR rect_y_kernel(RectView v, const double* src, double* dst) {  // src may alias dst
   __shared__ double lds[LDS_DOUBLES];
   const int lane = threadIdx.x;
@@ -259,6 +263,7 @@ __global__ void __launch_bounds__(64) QP_WAVES_ATTR rect_y_kernel(RectView v, co
   if (col + v.d.i0 == v.d.gnx - 1) scol += a * v.other_src[0][1];
   if (MODE != 3) {
     explicit64(e, gu, gd, cy, col_on ? scol : 0.0);
+    if (SRC) add_source_cols(v.bsrc + (long)t.b * ncell, t, v.d.nx, lane, v.bscale, e);
     store_cols(dplane, t, v.d.nx, lane, e);
   }
   if (QP_ABL & 8) return;
@@ -345,7 +350,7 @@ void build_chunk_table_len(const DirSpec& s, double a, int p, int L, double* tab
       const double e = (gk == 0 ? s.e_lo : 0.0) + (gk == s.n - 1 ? s.e_hi : 0.0);
       tab[T_CM * L + k] = lm ? a : 0.0;
       tab[T_CP * L + k] = lp ? a : 0.0;
-      tab[T_C0 * L + k] = 1.0 - a * ((lm ? 1.0 : 0.0) + (lp ? 1.0 : 0.0) + e);
+      tab[T_C0 * L + k] = 1.0 - a * ((lm ? 1.0 : 0.0) + (lp ? 1.0 : 0.0) + e) - s.c0_shift;
       tab[T_SRC * L + k] = a * ((gk == 0 ? s.s_lo : 0.0) + (gk == s.n - 1 ? s.s_hi : 0.0));
     } else {
       tab[T_W * L + k] = 1.0;
@@ -452,6 +457,18 @@ static double reduced_tables(const DirSpec& s, double a, int p0, int Ploc, doubl
     if ((mode) == 0) hipLaunchKernelGGL((NAME<ARG, 0, C>), __VA_ARGS__);           \
     else if ((mode) == 2) hipLaunchKernelGGL((NAME<ARG, 2, C>), __VA_ARGS__);      \
     else hipLaunchKernelGGL((NAME<ARG, 3, C>), __VA_ARGS__);                       \
+  } while (0)
+#define QP_LAUNCH_STREAMED_SRC(mode, compact, NAME, ARG, ...)                                              \
+  do {                                                                                                   \
+    if (compact) {                                                                                       \
+      if ((mode) == 0) hipLaunchKernelGGL((NAME<ARG, 0, true, true>), __VA_ARGS__);                      \
+      else if ((mode) == 2) hipLaunchKernelGGL((NAME<ARG, 2, true, true>), __VA_ARGS__);                 \
+      else hipLaunchKernelGGL((NAME<ARG, 3, true, true>), __VA_ARGS__);                                  \
+    } else {                                                                                             \
+      if ((mode) == 0) hipLaunchKernelGGL((NAME<ARG, 0, false, true>), __VA_ARGS__);                     \
+      else if ((mode) == 2) hipLaunchKernelGGL((NAME<ARG, 2, false, true>), __VA_ARGS__);                \
+      else hipLaunchKernelGGL((NAME<ARG, 3, false, true>), __VA_ARGS__);                                 \
+    }                                                                                                    \
   } while (0)
 // ... and for the plan's table form (compact: constant middle of every slot; otherwise every entry is fetched)
 #define QP_LAUNCH_STREAMED(mode, compact, NAME, ARG, ...)                          \
@@ -582,6 +599,11 @@ __global__ void __launch_bounds__(256) rect_combine_kernel(int ny, int nx, int n
 
 // Fine tiles are eligible on undecomposed grids whose extents are multiples of 64.  QPSIM_FINE_TILES=0 / 1 forces the
 // choice (1: whenever the plan qualifies); the default is the size rule measured on MI355X.
+static bool fine_tiles_allowed() {      // QPSIM_FINE_TILES=0 switches the fine kernels off everywhere
+  const char* e = getenv("QPSIM_FINE_TILES");
+  return !e || atoi(e) != 0;
+}
+
 static bool fine_tiles_wanted(int nfield, int ny, int nx) {
   if (ny % 64 != 0 || nx % 64 != 0) return false;
   if (const char* e = getenv("QPSIM_FINE_TILES")) return atoi(e) != 0;
@@ -592,8 +614,7 @@ static bool fine_tiles_wanted(int nfield, int ny, int nx) {
 
 // Tables, interface coefficients and interface arrays of the fine view; leaves plan->fine false (and no error) when the
 // plan does not qualify: chunks of 32 cells not decoupled at this r D, or a table without the compact form.
-static int fine_plan_create(qp_adi_rect_plan* plan, double r, const double* dcoef_host, const DirSpec (&coarse)[2],
-                            double c0_shift = 0.0) {
+static int fine_plan_create(qp_adi_rect_plan* plan, double r, const double* dcoef_host, const DirSpec (&coarse)[2]) {
   const RectView& v = plan->view;
   const int nfield = v.d.nfield, ny = v.d.ny, nx = v.d.nx;
   FineView& f = plan->fview;
@@ -629,8 +650,6 @@ static int fine_plan_create(qp_adi_rect_plan* plan, double r, const double* dcoe
           eawf[0] = 0.0;
           for (int k = 0; k < FS - 1; ++k) eav[k] = eav[k] * ev[k + 1] / ev[k];
           eav[FS - 1] = 0.0;
-          // Peaceman-Rachford iteration plans: the explicit operator is (I + a L) - c0_shift I
-          for (int k = 0; k < FS; ++k) tab[T_C0 * FS + k] -= c0_shift;
         }
         if (!table_is_compact_len(FS, tab.data())) return QP_OK;
         build_compact_table_len(FS, tab.data(), &ctab[(((size_t)d * nfield + b) * 4 + var) * 2 * CT_PART]);
@@ -720,8 +739,8 @@ int qp_adi_rect_plan_destroy(qp_adi_rect_plan* plan) {
   return QP_OK;
 }
 
-// pr_scale != 0: plan of one Peaceman-Rachford iteration (qp_adi_rect_plan_create_pr) - fine tiles are mandatory, the
-// 64 x 64 view gets no interface arrays, the carried plane may be borrowed from `share`.
+// pr_scale != 0: plan of one Peaceman-Rachford iteration (qp_adi_rect_plan_create_pr) - fine tiles wherever the grid
+// qualifies (the 64 x 64 view then gets no interface arrays), the carried plane may be borrowed from `share`.
 static int rect_plan_create_impl(int32_t ny, int32_t nx, int32_t nfield, double r, const double* dcoef_host,
                                  const double* bc_diag, const double* bc_src, int32_t force_banded, int32_t gny,
                                  int32_t gnx, int32_t j0, int32_t i0, double pr_scale, qp_adi_rect_plan* share,
@@ -747,8 +766,8 @@ static int rect_plan_create_impl(int32_t ny, int32_t nx, int32_t nfield, double 
                  stream_mode((size_t)nfield * ny * nx * sizeof(double))};
   plan->ncell = (long)ny * nx;
   // bc_* order: left, right, up, down  (x-faces then y-faces); specs describe the GLOBAL lines
-  DirSpec spec[2] = {{gnx, v.d.gpx, bc_diag[0], bc_diag[1], bc_src[0], bc_src[1]},
-                     {gny, v.d.gpy, bc_diag[2], bc_diag[3], bc_src[2], bc_src[3]}};
+  DirSpec spec[2] = {{gnx, v.d.gpx, bc_diag[0], bc_diag[1], bc_src[0], bc_src[1], pr_scale},
+                     {gny, v.d.gpy, bc_diag[2], bc_diag[3], bc_src[2], bc_src[3], pr_scale}};
   const int ploc[2] = {v.d.px, v.d.py};
   const int p0[2] = {i0 / TS, j0 / TS};
   for (int k = 0; k < 4; ++k) { plan->bc_diag[k] = bc_diag[k]; plan->bc_src[k] = bc_src[k]; }
@@ -810,9 +829,22 @@ static int rect_plan_create_impl(int32_t ny, int32_t nx, int32_t nfield, double 
   bool ok = upload(alpha, &plan->d_alpha) && upload(tab, &plan->d_tab) && upload(ctab, &plan->d_ctab);
   v.compact = all_compact ? 1 : 0;
   if (const char* e = getenv("QPSIM_COMPACT_TABLES")) v.compact = v.compact && atoi(e) != 0;   // 0: force the full form
+  v.bsrc = nullptr;
+  v.bscale = 0.0;
+  plan->pr_scale = pr_scale;
+  // fine tiles first: a plan that runs them needs no interface arrays for the 64 x 64 kernels when it is the plan of a
+  // Peaceman-Rachford iteration (nothing else ever runs on it)
+  if (ok && !decomposed && force_banded == 0 && ny % 64 == 0 && nx % 64 == 0 &&
+      (pr_scale != 0.0 ? fine_tiles_allowed() : fine_tiles_wanted(nfield, ny, nx))) {
+    const int rc = fine_plan_create(plan, r, dcoef_host, spec);
+    if (rc != QP_OK) {
+      qp_adi_rect_plan_destroy(plan);
+      return rc;
+    }
+  }
+  const bool lean = pr_scale != 0.0 && plan->fine;
   for (int d = 0; d < 2 && ok; ++d) {
     const size_t nlines = d == 0 ? ny : nx;
-    const bool lean = pr_scale != 0.0;       // the 64 x 64 kernels never run on such a plan
     ok = upload(lu[d], &plan->d_lu[d]) && upload(icoef[d], &plan->d_icoef[d]) &&
          zalloc(&plan->d_iface[d], lean ? 1 : (size_t)nfield * (2 * ploc[d] + 2) * nlines) &&
          zalloc(&plan->d_z[d], lean ? 1 : (size_t)nfield * 2 * ploc[d] * nlines) &&
@@ -839,21 +871,6 @@ static int rect_plan_create_impl(int32_t ny, int32_t nx, int32_t nfield, double 
     v.iface[d] = plan->d_iface[d];
     v.z[d] = plan->d_z[d];
     v.uhalo[d] = plan->d_uhalo[d];
-  }
-  plan->pr_scale = pr_scale;
-  if (!decomposed && force_banded == 0 && ny % 64 == 0 && nx % 64 == 0 &&
-      (pr_scale != 0.0 || fine_tiles_wanted(nfield, ny, nx))) {
-    const int rc = fine_plan_create(plan, r, dcoef_host, spec, pr_scale);
-    if (rc != QP_OK) {
-      qp_adi_rect_plan_destroy(plan);
-      return rc;
-    }
-  }
-  if (pr_scale != 0.0 && !plan->fine) {
-    qp_adi_rect_plan_destroy(plan);
-    set_error("qp_adi_rect_plan_create_pr: the grid does not qualify for fine tiles (extents multiples of 64, r D / (1/2 + p) "
-              "<~ 0.32 for every field)");
-    return QP_ERR_UNSUPPORTED;
   }
   *out = plan;
   return QP_OK;
@@ -885,9 +902,23 @@ int qp_adi_rect_plan_create_pr(int32_t ny, int32_t nx, int32_t nfield, double r,
 // u <- one Peaceman-Rachford iteration towards A u = b (see qp_adi_rect_plan_create_pr), u and b [nfield][ny*nx].
 int qp_adi_rect_pr_iteration(qp_adi_rect_plan* plan, double* u, const double* b, void* stream_) {
   QP_REQUIRE(plan && u && b, "plan, u, b must be non-NULL");
-  QP_REQUIRE(plan->pr_scale != 0.0 && plan->fine, "not a Peaceman-Rachford plan (qp_adi_rect_plan_create_pr)");
+  QP_REQUIRE(plan->pr_scale != 0.0, "not a Peaceman-Rachford plan (qp_adi_rect_plan_create_pr)");
   using namespace qp;
   hipStream_t stream = (hipStream_t)stream_;
+  if (!plan->fine) {      // 64 x 64 tiles: any extents, banded reduced systems where the chunks do not decouple
+    RectView v = plan->view;
+    v.bsrc = b;
+    v.bscale = plan->pr_scale;
+    const unsigned ctiles = (unsigned)((long)v.d.nfield * v.d.py * v.d.px);
+    double* cw = plan->d_work;
+    QP_LAUNCH_STREAMED_SRC(v.d.stream, v.compact, rect_y_kernel, 0, dim3(ctiles), dim3(64), 0, stream, v, (const double*)u, cw);
+    int rc = qp_adi_rect_phase(plan, QP_ADI_REDUCED_X, u, stream_);
+    if (rc) return rc;
+    QP_LAUNCH_STREAMED_SRC(v.d.stream, v.compact, rect_x_kernel, true, dim3(ctiles), dim3(64), 0, stream, v, cw);
+    rc = qp_adi_rect_phase(plan, QP_ADI_REDUCED_Y, u, stream_);
+    if (rc) return rc;
+    return qp_adi_rect_phase(plan, QP_ADI_SWEEP_Y_EXIT, u, stream_);
+  }
   FineView f = plan->fview;
   f.bsrc = b;
   f.bscale = plan->pr_scale;

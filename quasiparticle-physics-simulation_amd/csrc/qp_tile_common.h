@@ -290,6 +290,21 @@ __device__ __forceinline__ void store_cols(double* __restrict__ base, const Tile
   }
 }
 
+// v += scale * (tile of `base`), same tile / bounds as load_cols (source plane of the Peaceman-Rachford passes)
+__device__ __forceinline__ void add_source_cols(const double* __restrict__ base, const TileCoord& t, int nx, int lane,
+                                                double scale, double (&v)[TS]) {
+  const double* p = base + (long)t.j0 * nx + t.i0;
+  const unsigned l = (unsigned)lane;
+  if (t.nr == TS && t.nc == TS) {
+#pragma unroll
+    for (int r = 0; r < TS; ++r) v[r] = fma(scale, (p + (long)r * nx)[l], v[r]);
+  } else if (lane < t.nc) {
+#pragma unroll
+    for (int r = 0; r < TS; ++r)
+      if (r < t.nr) v[r] = fma(scale, (p + (long)r * nx)[l], v[r]);
+  }
+}
+
 // host: fills the T_NSLOT x TS table of chunk `p` of a line described by (n, P, end-face terms); returns
 // g[0], g[last], h[0], h[last] through `ends`
 struct DirSpec {
@@ -297,6 +312,7 @@ struct DirSpec {
   int P;          // chunks
   double e_lo, e_hi;   // BC diagonal terms of the two end faces (1/dx^2 units)
   double s_lo, s_hi;   // BC sources of the two end faces
+  double c0_shift = 0.0;   // explicit operator (I + a L) - c0_shift I (Peaceman-Rachford iteration plans)
 };
 void build_chunk_table(const DirSpec& s, double a, int p, double* tab, double ends[4]);
 

@@ -243,7 +243,8 @@ class RectPlan:
         _hip.check(lib.qp_adi_rect_plan_create_pr(ny, nx, nfield, float(r), dc, bd, float(p),
                                                   share.handle if share is not None else None, C.byref(self._h)),
                    "qp_adi_rect_plan_create_pr")
-        self.decoupled, self.fine, self.p = (True, True), True, float(p)
+        self.decoupled = (bool(lib.qp_adi_rect_plan_decoupled(self._h, 0)), bool(lib.qp_adi_rect_plan_decoupled(self._h, 1)))
+        self.fine, self.p = bool(lib.qp_adi_rect_plan_fine(self._h)), float(p)
         return self
 
     @property
@@ -378,20 +379,20 @@ class DiffusionOperator:
 
 def _pr_cycle(op: "DiffusionOperator", reduction: float):
     """Peaceman-Rachford plans of ``op`` for a worst-case error reduction ``reduction`` per cycle (cached), or None when the
-    operator does not qualify: not a full rectangle with one D per field and one BC per side, a boundary diagonal term
-    below zero (H, V no longer bounded below by 1/2), extents that are not multiples of 64, or chunks of 32 cells that do
-    not decouple at r D / (1/2 + p)."""
+    operator does not qualify: not a full rectangle with one D per field and one BC per side (Lx, Ly would not commute),
+    or a boundary diagonal term below zero (H, V no longer bounded below by 1/2)."""
     key = float(reduction)
     if key in op._pr_cycles:
         return op._pr_cycles[key]
     cycle = None
     eng = op.engine
-    if (op.rect is not None and op._sides is not None and eng.ny % 64 == 0 and eng.nx % 64 == 0
-            and min(op._sides[0]) >= 0.0 and os.environ.get("QPSIM_CN_PR", "1") != "0"):
+    if (op.rect is not None and op._sides is not None and min(op._sides[0]) >= 0.0
+            and os.environ.get("QPSIM_CN_PR", "1") != "0"):
         dc = op.dcoef.cpu().numpy()
         amax = op.r * float(dc.max())
         if amax > 0.0:
-            beta = 0.5 + amax * max(4.0, 2.0 + max(op._sides[0]))
+            emax = max(op._sides[0])
+            beta = 0.5 + amax * max(4.0, 2.0 + emax, 2.0 * emax)      # Gershgorin; 2 e: a direction one cell thick
             ps, worst = peaceman_rachford_parameters(0.5, beta, reduction)
             if worst <= reduction:
                 try:
@@ -402,7 +403,7 @@ def _pr_cycle(op: "DiffusionOperator", reduction: float):
                                                                     op._sides[0], p, share=plans[0] if plans else None))
                     cycle = plans
                 except _hip.QPHipError as exc:
-                    if exc.status != -3:      # QP_ERR_UNSUPPORTED: no fine tiles for this operator
+                    if exc.status != -3:      # QP_ERR_UNSUPPORTED
                         raise
     op._pr_cycles[key] = cycle
     return cycle

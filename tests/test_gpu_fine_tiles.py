@@ -112,14 +112,43 @@ def test_exact_cn_step_on_fine_tiles_matches_superlu(O, monkeypatch, ny, nx, D, 
     assert rel_err(eng.download_packed(a)[0], want) < 1e-11
 
 
-def test_peaceman_rachford_cycle_is_refused_where_it_does_not_apply(monkeypatch):
-    """Stiff step (r D / (1/2 + p) above the fine-tile limit), a negative boundary diagonal term, extents that are not
-    multiples of 64: no cycle, the step runs the preconditioned iteration."""
+@pytest.mark.parametrize("ny,nx,D", [(70, 130, 2.0), (128, 192, 40.0), (1, 100, 6.0), (129, 257, 6.0), (64, 63, 0.5)])
+def test_peaceman_rachford_cycle_on_64_tiles_matches_superlu(O, ny, nx, D):
+    """The cycle on the 64 x 64 kernels (`rect_*_kernel<..., SRC>`): ragged extents, remainder chunks, the banded reduced
+    solve of stiff steps (r D = 2.7), one-cell-thick grids - against the oracle's SuperLU solve, three steps."""
     from qpsim_amd.engine import DiffusionOperator, _pr_cycle
+    dx, dt = 0.9, 0.11
+    mask, edges, bcs, eng = _problem(ny, nx, dx)
+    ops = O.build_grid_ops(mask, edges, bcs, dx)
+    op = DiffusionOperator(eng, 2, dt, dcoef=[D, 0.4 * D])
+    cycle = _pr_cycle(op, 1e-11)
+    assert cycle is not None and not all(p.fine for p in cycle)      # (stiff: the large-p plans of the cycle do qualify)
+    rng = np.random.default_rng(ny + nx)
+    u0 = rng.random((2, ny * nx))
+    a = eng.upload_packed(u0)
+    for _ in range(3):
+        eng.cn_exact_step(op, a)
+    got = eng.download_packed(a)
+    for k, Dk in enumerate([D, 0.4 * D]):
+        st = O.CNStepper(ops, Dk, dt)
+        want = u0[k].copy()
+        for _ in range(3):
+            want = st.step(want)
+        assert rel_err(got[k], want) < 2e-11, k
+
+
+def test_peaceman_rachford_cycle_is_refused_where_it_does_not_apply():
+    """Masked grids (Lx, Ly do not commute) and per-cell diffusivities have no cycle: the preconditioned iteration runs."""
+    from qpsim_amd.engine import DiffusionOperator, Engine, _pr_cycle, compile_geometry
+    from qpsim_amd.geometry import extract_edge_segments
+    from qpsim_amd.models import BoundaryCondition
     _, _, _, eng = _problem(128, 128)
     assert _pr_cycle(DiffusionOperator(eng, 1, 0.11, dcoef=[1.0]), 1e-11) is not None
-    assert _pr_cycle(DiffusionOperator(eng, 1, 0.11, dcoef=[40.0]), 1e-11) is None
-    _, _, _, eng2 = _problem(128, 100)
+    assert _pr_cycle(DiffusionOperator(eng, 1, 0.11, dfield=np.full((1, 128 * 128), 1.0)), 1e-11) is None
+    mask = np.ones((96, 96), dtype=bool)
+    mask[30:50, 40:70] = False
+    edges = extract_edge_segments(mask)
+    eng2 = Engine(compile_geometry(mask, edges, {e.edge_id: BoundaryCondition("reflective") for e in edges}, 1.0))
     assert _pr_cycle(DiffusionOperator(eng2, 1, 0.11, dcoef=[1.0]), 1e-11) is None
 
 
