@@ -267,6 +267,10 @@ int qp_adi_rect_plan_fine(const qp_adi_rect_plan* plan);
 int qp_adi_rect_plan_create_pr(int32_t ny, int32_t nx, int32_t nfield, double r, const double* dcoef_host,
                                const double* bc_diag, double p, qp_adi_rect_plan* share, qp_adi_rect_plan** out);
 int qp_adi_rect_pr_iteration(qp_adi_rect_plan* plan, double* u, const double* b, void* stream);
+/* One whole cycle, plans[0 .. nplans) in order, u overwritten with the last iterate.  When every plan runs the fine tiles
+ * the iterations are carried (the y-pass of iteration j forms the right-hand side of iteration j + 1: two passes and
+ * 6 plane transfers per iteration instead of three passes and 8); otherwise one qp_adi_rect_pr_iteration per plan. */
+int qp_adi_rect_pr_cycle(qp_adi_rect_plan* const* plans, int32_t nplans, double* u, const double* b, void* stream);
 int qp_adi_rect_steps(qp_adi_rect_plan* plan, double* u, int32_t nsteps, void* stream);
 /* qp_stencil_combine for the plan's operator without per-cell geometry arrays (positions decide which side term applies):
  * out = c0 u + cx (a Lx u) + cy (a Ly u) + cs a S + cr rin on [nfield][ny*nx]; with norm_out non-NULL also

@@ -899,6 +899,55 @@ int qp_adi_rect_plan_create_pr(int32_t ny, int32_t nx, int32_t nfield, double r,
   return rect_plan_create_impl(ny, nx, nfield, r * s, dcoef_host, bc_diag, zero, 0, ny, nx, 0, 0, s, share, out);
 }
 
+// u <- one CYCLE of Peaceman-Rachford iterations, plans[0 .. nplans) in order.  When every plan runs the fine tiles the
+// iterations are carried: the y-kernel of iteration j leaves the right-hand side of the x-solve of iteration j + 1
+// (fine_y_next_kernel), two passes per iteration instead of three (6 instead of 8 plane transfers); otherwise one
+// qp_adi_rect_pr_iteration per plan.
+int qp_adi_rect_pr_cycle(qp_adi_rect_plan* const* plans, int32_t nplans, double* u, const double* b, void* stream_) {
+  QP_REQUIRE(plans && nplans >= 1 && u && b, "plans, u, b must be non-NULL and nplans >= 1");
+  using namespace qp;
+  bool carried = true;
+  for (int j = 0; j < nplans; ++j) {
+    QP_REQUIRE(plans[j] && plans[j]->pr_scale != 0.0, "not a Peaceman-Rachford plan (qp_adi_rect_plan_create_pr)");
+    QP_REQUIRE(plans[j]->ncell == plans[0]->ncell && plans[j]->view.d.nfield == plans[0]->view.d.nfield &&
+                   plans[j]->view.d.nx == plans[0]->view.d.nx, "the plans of a cycle must have one shape");
+    carried = carried && plans[j]->fine;
+  }
+  if (const char* e = getenv("QPSIM_PR_CARRIED")) carried = carried && atoi(e) != 0;
+  if (!carried) {
+    for (int j = 0; j < nplans; ++j) {
+      const int rc = qp_adi_rect_pr_iteration(plans[j], u, b, stream_);
+      if (rc) return rc;
+    }
+    return QP_OK;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  double* w = plans[0]->d_work;
+  const FineView& f0 = plans[0]->fview;
+  const unsigned tiles = (unsigned)((long)f0.nfield * (f0.ny / 64) * f0.px);
+  auto view = [&](int j) {
+    FineView f = plans[j]->fview;
+    f.bsrc = b;
+    f.bscale = plans[j]->pr_scale;
+    return f;
+  };
+  FineView cur = view(0);
+  QP_LAUNCH_FINE_SRC(cur.stream, fine_y_kernel, 0, dim3(tiles), dim3(64), 0, stream, cur, (const double*)u, w);
+  for (int j = 0; j < nplans; ++j) {
+    QP_LAUNCH_FINE_SRC(cur.stream, fine_x_kernel, true, dim3(tiles), dim3(64), 0, stream, cur, w);
+    if (j + 1 < nplans) {
+      const FineView nxt = view(j + 1);
+      if (cur.stream == 0) hipLaunchKernelGGL((fine_y_next_kernel<0>), dim3(tiles), dim3(64), 0, stream, cur, nxt, w);
+      else if (cur.stream == 2) hipLaunchKernelGGL((fine_y_next_kernel<2>), dim3(tiles), dim3(64), 0, stream, cur, nxt, w);
+      else hipLaunchKernelGGL((fine_y_next_kernel<3>), dim3(tiles), dim3(64), 0, stream, cur, nxt, w);
+      cur = nxt;
+    } else {
+      QP_LAUNCH_FINE(cur.stream, fine_y_kernel, 2, dim3(tiles), dim3(64), 0, stream, cur, (const double*)w, u);
+    }
+  }
+  return check_launch("qp_adi_rect_pr_cycle");
+}
+
 // u <- one Peaceman-Rachford iteration towards A u = b (see qp_adi_rect_plan_create_pr), u and b [nfield][ny*nx].
 int qp_adi_rect_pr_iteration(qp_adi_rect_plan* plan, double* u, const double* b, void* stream_) {
   QP_REQUIRE(plan && u && b, "plan, u, b must be non-NULL");

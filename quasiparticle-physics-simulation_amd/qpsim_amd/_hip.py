@@ -87,6 +87,7 @@ SIGNATURES = {
                                              C.POINTER(C.c_double), C.c_double, C.POINTER(RectPlan),
                                              C.POINTER(C.POINTER(RectPlan))]),
     "qp_adi_rect_pr_iteration": (C.c_int, [C.POINTER(RectPlan), c_dp, c_dp, c_dp]),
+    "qp_adi_rect_pr_cycle": (C.c_int, [C.POINTER(C.POINTER(RectPlan)), C.c_int32, c_dp, c_dp, c_dp]),
     "qp_adi_rect_plan_destroy": (C.c_int, [C.POINTER(RectPlan)]),
     "qp_adi_rect_steps": (C.c_int, [C.POINTER(RectPlan), c_dp, C.c_int32, c_dp]),
     "qp_adi_rect_solve": (C.c_int, [C.POINTER(RectPlan), c_dp, c_dp]),

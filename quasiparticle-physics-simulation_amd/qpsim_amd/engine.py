@@ -650,9 +650,9 @@ class Engine:
         target = getattr(op, "_pr_target", max(100.0 * rtol, 1e-15))
         cycle = _pr_cycle(op, target) if rho > self.CHEBYSHEV_FROM else None
         if cycle is not None:
-            for plan in cycle:
-                _hip.check(self.lib.qp_adi_rect_pr_iteration(plan.handle, _ptr(v), _ptr(R), self.stream),
-                           "qp_adi_rect_pr_iteration")
+            handles = (C.POINTER(_hip.RectPlan) * len(cycle))(*[plan.handle for plan in cycle])
+            _hip.check(self.lib.qp_adi_rect_pr_cycle(handles, len(cycle), _ptr(v), _ptr(R), self.stream),
+                       "qp_adi_rect_pr_cycle")
             self.stencil(op, v, res, -1.0, 1.0, 1.0, 0.0, rin=R, cr=1.0, norm_out=norms[1:2])
             scale, err = (float(x) for x in norms.cpu())
             if not np.isfinite(err):

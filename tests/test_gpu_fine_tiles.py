@@ -222,3 +222,30 @@ def test_fine_tiles_fuzz_against_coarse_tiles_and_general_kernels(monkeypatch, s
     ha, hb, hc = (eng.download_packed(t) for t in (a, b, c))
     assert rel_err(ha, hb) < 5e-14, (ny, nx, side_bc, Dc, nsteps)
     assert rel_err(ha, hc) < 5e-13, (ny, nx, side_bc, Dc, nsteps)
+
+
+def test_carried_and_three_pass_peaceman_rachford_cycles_agree(monkeypatch):
+    """`qp_adi_rect_pr_cycle`: the carried form (the y-pass of iteration j leaves the right-hand side of iteration j + 1,
+    `fine_y_next_kernel`) against one three-pass `qp_adi_rect_pr_iteration` per parameter, same plans, same data."""
+    import ctypes as C
+    from qpsim_amd import _hip
+    from qpsim_amd.engine import DiffusionOperator, _pr_cycle, _ptr
+    _, _, _, eng = _problem(192, 256)
+    op = DiffusionOperator(eng, 3, 0.11, dcoef=[4.0, 1.0, 0.0])
+    cycle = _pr_cycle(op, 1e-9)
+    assert cycle is not None and all(p.fine for p in cycle) and len(cycle) >= 4
+    rng = np.random.default_rng(11)
+    u0, b0 = rng.random((3, 192 * 256)), rng.random((3, 192 * 256))
+    handles = (C.POINTER(_hip.RectPlan) * len(cycle))(*[p.handle for p in cycle])
+    out = []
+    for carried in ("1", "0"):
+        monkeypatch.setenv("QPSIM_PR_CARRIED", carried)
+        u, b = eng.upload_packed(u0), eng.upload_packed(b0)
+        _hip.check(eng.lib.qp_adi_rect_pr_cycle(handles, len(cycle), _ptr(u), _ptr(b), eng.stream), "qp_adi_rect_pr_cycle")
+        out.append(eng.download_packed(u))
+    assert rel_err(out[0], out[1]) < 1e-13
+    # and the cycle does what it promises: A u = b to the cycle's reduction (A = I - r D L, checked with the general stencil)
+    u = eng.upload_packed(out[0])
+    res = eng.upload_packed(np.zeros_like(u0))
+    eng.stencil(op, u, res, 1.0, -1.0, -1.0, 0.0)      # res = u - a Lx u - a Ly u = A u (sources are part of b)
+    assert rel_err(eng.download_packed(res), b0) < 1e-7
