@@ -638,7 +638,6 @@ class Engine:
         v = self.scratch("cn_v", n).view(op.nfield, self.ncell)
         norms = self.scratch("cn_norms", 2)           # [max |R|, max |R - A v|], both read back in one transfer
         self.stencil(op, u, R, 1.0, 1.0, 1.0, 2.0, norm_out=norms[0:1])
-        v.copy_(u)
         rho = self.cn_contraction_bound(op)
         # Full rectangles (commuting Lx, Ly): one cycle of Peaceman-Rachford iterations with Jordan's parameters on the
         # spectrum of I/2 - r D L_dir - 8 plane transfers per iteration against 13 of the preconditioned iteration below and
@@ -650,20 +649,22 @@ class Engine:
         target = getattr(op, "_pr_target", max(100.0 * rtol, 1e-15))
         cycle = _pr_cycle(op, target) if rho > self.CHEBYSHEV_FROM else None
         if cycle is not None:
+            # in place on u (the right-hand side R is already formed): no copies when the cycle suffices
             handles = (C.POINTER(_hip.RectPlan) * len(cycle))(*[plan.handle for plan in cycle])
-            _hip.check(self.lib.qp_adi_rect_pr_cycle(handles, len(cycle), _ptr(v), _ptr(R), self.stream),
+            _hip.check(self.lib.qp_adi_rect_pr_cycle(handles, len(cycle), _ptr(u), _ptr(R), self.stream),
                        "qp_adi_rect_pr_cycle")
-            self.stencil(op, v, res, -1.0, 1.0, 1.0, 0.0, rin=R, cr=1.0, norm_out=norms[1:2])
+            self.stencil(op, u, res, -1.0, 1.0, 1.0, 0.0, rin=R, cr=1.0, norm_out=norms[1:2])
             scale, err = (float(x) for x in norms.cpu())
             if not np.isfinite(err):
                 raise FloatingPointError("exact-CN iteration diverged (non-finite residual)")
             if err <= rtol * scale:
                 if err <= 0.01 * rtol * scale and target < 1e-3:
                     op._pr_target = target * 30.0
-                u.copy_(v)
                 return len(cycle)
             op._pr_target = max(target / 30.0, 1e-15)
+            v.copy_(u)
         else:
+            v.copy_(u)
             self.adi_step(op, v)
         if rho > self.CHEBYSHEV_FROM and not getattr(op, "_cn_plain", False):
             its = self._cn_chebyshev(op, R, res, v, norms, rho, rtol, max_iter)
