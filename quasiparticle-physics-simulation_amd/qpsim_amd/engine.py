@@ -405,6 +405,8 @@ def _pr_cycle(op: "DiffusionOperator", reduction: float):
                 except _hip.QPHipError as exc:
                     if exc.status != -3:      # QP_ERR_UNSUPPORTED
                         raise
+    while len(op._pr_cycles) >= 2:      # the adaptive cycle length moves between neighbouring targets: keep two sets of plans
+        op._pr_cycles.pop(next(iter(op._pr_cycles)))
     op._pr_cycles[key] = cycle
     return cycle
 
