@@ -535,51 +535,76 @@ __global__ void __launch_bounds__(256) rect_combine_kernel(int ny, int nx, int n
                                                            double* __restrict__ part) {
   const long ncell = (long)ny * nx;
   double m = 0.0;
-  // a block walks (field, row) pairs, its threads the cells of the row: no 64-bit division per cell
-  for (int line = blockIdx.x; line < nfield * ny; line += gridDim.x) {
-    const int b = line / ny, j = line - b * ny;
-    const double a = alpha[b];
-    const double* ub = u + (long)b * ncell + (long)j * nx;
-    const long t0 = (long)b * ncell + (long)j * nx;
-    const double* rb = rin ? rin + t0 : nullptr;
-    double* ob = out + t0;
-    auto cell = [&](int i, double um, double up, double upp, double uu, double ud) {
-      double lx = 0.0, ly = 0.0, src = 0.0;
-      if (i > 0) lx += um - up; else { lx -= g.dl * up; src += g.sl; }
-      if (i < nx - 1) lx += upp - up; else { lx -= g.dr * up; src += g.sr; }
-      if (j > 0) ly += uu - up; else { ly -= g.du * up; src += g.su; }
-      if (j < ny - 1) ly += ud - up; else { ly -= g.dd * up; src += g.sd; }
-      return c0 * up + cx * (a * lx) + cy * (a * ly) + cs * (a * src);
-    };
-    if ((nx & 3) == 0) {
-      // four cells per thread: the row above, the row itself and the row below as two 16-byte loads each, the two
-      // neighbours beyond the quad as 8-byte loads (cache hits) - 3 memory instructions per cell instead of 7
-      for (int i = 4 * threadIdx.x; i < nx; i += 4 * blockDim.x) {
-        const double2 c0v = *reinterpret_cast<const double2*>(ub + i), c1v = *reinterpret_cast<const double2*>(ub + i + 2);
-        double2 u0 = c0v, u1 = c1v, d0 = c0v, d1 = c1v;
-        if (j > 0) { u0 = *reinterpret_cast<const double2*>(ub + i - nx); u1 = *reinterpret_cast<const double2*>(ub + i + 2 - nx); }
-        if (j < ny - 1) { d0 = *reinterpret_cast<const double2*>(ub + i + nx); d1 = *reinterpret_cast<const double2*>(ub + i + 2 + nx); }
-        const double left = i > 0 ? ub[i - 1] : 0.0, right = i + 4 < nx ? ub[i + 4] : 0.0;
-        double r[4] = {cell(i, left, c0v.x, c0v.y, u0.x, d0.x), cell(i + 1, c0v.x, c0v.y, c1v.x, u0.y, d0.y),
-                       cell(i + 2, c0v.y, c1v.x, c1v.y, u1.x, d1.x), cell(i + 3, c1v.x, c1v.y, right, u1.y, d1.y)};
-        if (cr != 0.0) {
-          const double2 q0 = *reinterpret_cast<const double2*>(rb + i), q1 = *reinterpret_cast<const double2*>(rb + i + 2);
-          r[0] += cr * q0.x; r[1] += cr * q0.y; r[2] += cr * q1.x; r[3] += cr * q1.y;
-        }
-        *reinterpret_cast<double2*>(ob + i) = make_double2(r[0], r[1]);
-        *reinterpret_cast<double2*>(ob + i + 2) = make_double2(r[2], r[3]);
+  auto cell = [&](double a, int i, int j, double um, double up, double upp, double uu, double ud) {
+    double lx = 0.0, ly = 0.0, src = 0.0;
+    if (i > 0) lx += um - up; else { lx -= g.dl * up; src += g.sl; }
+    if (i < nx - 1) lx += upp - up; else { lx -= g.dr * up; src += g.sr; }
+    if (j > 0) ly += uu - up; else { ly -= g.du * up; src += g.su; }
+    if (j < ny - 1) ly += ud - up; else { ly -= g.dd * up; src += g.sd; }
+    return c0 * up + cx * (a * lx) + cy * (a * ly) + cs * (a * src);
+  };
+  if ((nx & 3) == 0) {
+    // A block walks bands of RB rows of one field; a thread owns a strip 4 cells wide and walks down the band with the row
+    // above, the row itself and the row below in registers: every row of u is loaded once per band (+2 halo rows per RB)
+    // as two 16-byte loads per thread, the two cells beside the strip as 8-byte loads (cache hits) - no per-cell division.
+    constexpr int RB = 8;
+    const int bands_per_field = (ny + RB - 1) / RB;
+    const int chunk = 4 * blockDim.x, chunks = (nx + chunk - 1) / chunk;      // column chunks of one strip per thread
+    for (long item = blockIdx.x; item < (long)nfield * bands_per_field * chunks; item += gridDim.x) {
+      const int band = (int)(item / chunks), ch = (int)(item - (long)band * chunks);
+      const int b = band / bands_per_field, j0 = (band - b * bands_per_field) * RB;
+      const double a = alpha[b];
+      const double* ub0 = u + (long)b * ncell;
+      const int i = ch * chunk + 4 * threadIdx.x;
+      if (i < nx) {
+        auto load = [&](int j, double2& q0, double2& q1) {
+          const double* p = ub0 + (long)j * nx + i;
+          q0 = *reinterpret_cast<const double2*>(p);
+          q1 = *reinterpret_cast<const double2*>(p + 2);
+        };
+        double2 c0v, c1v, u0, u1, d0, d1;
+        load(j0, c0v, c1v);
+        u0 = c0v; u1 = c1v;
+        if (j0 > 0) load(j0 - 1, u0, u1);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const double v = fabs(r[q]);
-          m = (v != v) ? __builtin_huge_val() : fmax(m, v);
+        for (int r = 0; r < RB; ++r) {
+          const int j = j0 + r;
+          if (j >= ny) break;
+          d0 = c0v; d1 = c1v;
+          if (j < ny - 1) load(j + 1, d0, d1);
+          const double* ub = ub0 + (long)j * nx;
+          const double left = i > 0 ? ub[i - 1] : 0.0, right = i + 4 < nx ? ub[i + 4] : 0.0;
+          double res[4] = {cell(a, i, j, left, c0v.x, c0v.y, u0.x, d0.x), cell(a, i + 1, j, c0v.x, c0v.y, c1v.x, u0.y, d0.y),
+                           cell(a, i + 2, j, c0v.y, c1v.x, c1v.y, u1.x, d1.x), cell(a, i + 3, j, c1v.x, c1v.y, right, u1.y, d1.y)};
+          const long t0 = (long)b * ncell + (long)j * nx + i;
+          if (cr != 0.0) {
+            const double2 q0 = *reinterpret_cast<const double2*>(rin + t0), q1 = *reinterpret_cast<const double2*>(rin + t0 + 2);
+            res[0] += cr * q0.x; res[1] += cr * q0.y; res[2] += cr * q1.x; res[3] += cr * q1.y;
+          }
+          *reinterpret_cast<double2*>(out + t0) = make_double2(res[0], res[1]);
+          *reinterpret_cast<double2*>(out + t0 + 2) = make_double2(res[2], res[3]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const double v = fabs(res[q]);
+            m = (v != v) ? __builtin_huge_val() : fmax(m, v);
+          }
+          u0 = c0v; u1 = c1v;
+          c0v = d0; c1v = d1;
         }
       }
-    } else {
+    }
+  } else {
+    // a block walks (field, row) pairs, its threads the cells of the row
+    for (int line = blockIdx.x; line < nfield * ny; line += gridDim.x) {
+      const int b = line / ny, j = line - b * ny;
+      const double a = alpha[b];
+      const double* ub = u + (long)b * ncell + (long)j * nx;
+      const long t0 = (long)b * ncell + (long)j * nx;
       for (int i = threadIdx.x; i < nx; i += blockDim.x) {
-        double res = cell(i, i > 0 ? ub[i - 1] : 0.0, ub[i], i < nx - 1 ? ub[i + 1] : 0.0, j > 0 ? ub[i - nx] : 0.0,
+        double res = cell(a, i, j, i > 0 ? ub[i - 1] : 0.0, ub[i], i < nx - 1 ? ub[i + 1] : 0.0, j > 0 ? ub[i - nx] : 0.0,
                           j < ny - 1 ? ub[i + nx] : 0.0);
-        if (cr != 0.0) res += cr * rb[i];
-        ob[i] = res;
+        if (cr != 0.0) res += cr * rin[t0 + i];
+        out[t0 + i] = res;
         const double v = fabs(res);
         m = (v != v) ? __builtin_huge_val() : fmax(m, v);
       }
@@ -1087,7 +1112,9 @@ int qp_adi_rect_combine(qp_adi_rect_plan* plan, const double* u, const double* r
   using namespace qp;
   hipStream_t stream = (hipStream_t)stream_;
   const RectView& v = plan->view;
-  long blocks = (long)v.d.nfield * v.d.ny;  // one (field, row) pair per block and trip
+  // one band of 8 rows (row lengths that are multiples of 4) or one row per block and trip
+  long blocks = (v.d.nx & 3) == 0 ? (long)v.d.nfield * ((v.d.ny + 7) / 8) * ((v.d.nx + 1023) / 1024)
+                                  : (long)v.d.nfield * v.d.ny;
   if (blocks > 1024) blocks = 1024;         // = the partial slots of the reduction workspace
   QP_REQUIRE(((uintptr_t)u | (uintptr_t)out | (uintptr_t)rin) % 16 == 0, "u, rin, out must be 16-byte aligned");
   RectSides g{plan->bc_diag[0], plan->bc_diag[1], plan->bc_diag[2], plan->bc_diag[3],
