@@ -228,3 +228,23 @@ def test_peaceman_rachford_parameters_meet_their_bound_on_a_commuting_model_prob
         us = np.linalg.solve(H + p * I, b - (V - p * I) @ u)
         u = np.linalg.solve(V + p * I, b - (H - p * I) @ us)
     assert np.linalg.norm(u - x) <= 1.01 * worst * np.linalg.norm(x)
+
+
+def test_fine_tile_block_mapping_is_a_bijection_that_keeps_super_tiles_on_one_xcd_label():
+    """`fine_block` (csrc/qp_adi_fine.inc), restated: block -> (64 x 64 super-tile, half).  Every (super-tile, half) is hit
+    exactly once, and both halves of a super-tile come from blocks with equal `blockIdx % 8` (the XCD label under round-robin
+    dispatch) in every full group of 8 super-tiles - which is what keeps a tile on one XCD's L2 from pass to pass."""
+    def fine_block(bid, ns):
+        group, r = bid >> 4, bid & 15
+        m = min(8, ns - group * 8)
+        return group * 8 + r % m, r // m
+
+    for ns in (1, 2, 5, 8, 9, 16, 23, 64, 1000):
+        seen = {}
+        for bid in range(2 * ns):
+            S, sub = fine_block(bid, ns)
+            assert 0 <= S < ns and sub in (0, 1) and (S, sub) not in seen
+            seen[(S, sub)] = bid
+        assert len(seen) == 2 * ns
+        for S in range(8 * (ns // 8)):
+            assert seen[(S, 0)] % 8 == seen[(S, 1)] % 8 == S % 8
