@@ -22,8 +22,13 @@
 // extra pass (the "entry" variant of the y-kernel forms rhs1 from u and its two halo rows).
 //
 // Global accesses: lane <-> column, one 512 B row segment per wave instruction.  x-direction work needs
-// lane <-> row, so the tile goes through LDS (pitch 65 doubles: conflict-free both ways) at each change of
+// lane <-> row, so the tile is transposed (v_permlane32_swap + 32 x 33 LDS blocks, transpose64) at each change of
 // direction.  y-direction work happens entirely in registers (64 doubles per lane).
+//
+// Where the carried planes stay cached (<= 192 MiB) and r D <~ 0.32 the same passes run on FINE tiles - chunks of 32
+// cells, 32 x 64 / 64 x 32 tiles, XCD-consistent block mapping (qp_adi_fine.inc); and the plans of the Peaceman-Rachford
+// cycle for the unsplit Crank-Nicolson system (qp_adi_rect_plan_create_pr, qp_adi_rect_pr_cycle) reuse both families with
+// a source-plane argument.
 #include <algorithm>
 #include <cmath>
 #include <vector>
