@@ -249,3 +249,33 @@ def test_carried_and_three_pass_peaceman_rachford_cycles_agree(monkeypatch):
     res = eng.upload_packed(np.zeros_like(u0))
     eng.stencil(op, u, res, 1.0, -1.0, -1.0, 0.0)      # res = u - a Lx u - a Ly u = A u (sources are part of b)
     assert rel_err(eng.download_packed(res), b0) < 1e-7
+
+
+def test_default_scheme_at_full_size_solves_the_unsplit_system():
+    """4096^2 (BASELINE's headline grid), default unsplit-CN step through the carried Peaceman-Rachford cycle: the result
+    satisfies (I - rL) u' = (I + rL) u to 1e-12 as evaluated by the GENERAL stencil kernel (per-cell geometry arrays - code
+    that shares nothing with the cycle or with `qp_adi_rect_combine`), conserves the total under reflective walls and obeys
+    the maximum principle.  Size-independent properties: no oracle reaches this size."""
+    import torch
+    from qpsim_amd.engine import DiffusionOperator, Engine, _pr_cycle, compile_geometry
+    from qpsim_amd.geometry import extract_edge_segments
+    from qpsim_amd.models import BoundaryCondition
+    N = 4096
+    mask = np.ones((N, N), dtype=bool)
+    edges = extract_edge_segments(mask)
+    eng = Engine(compile_geometry(mask, edges, {e.edge_id: BoundaryCondition("reflective") for e in edges}, 1.0))
+    op = DiffusionOperator(eng, 1, 0.1, dcoef=[6.0])
+    gen = DiffusionOperator(eng, 1, 0.1, dcoef=[6.0], allow_fast=False)
+    assert op.rect.fine and gen.rect is None and gen.tile is None
+    cycle = _pr_cycle(op, 1e-11)
+    assert cycle is not None and all(p.fine for p in cycle)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    u0 = (1e-4 * (1.0 + torch.rand(1, N * N, generator=g, dtype=torch.float64))).cuda()
+    u = u0.clone()
+    eng.cn_exact_step(op, u)
+    lhs, rhs = torch.empty_like(u), torch.empty_like(u)
+    eng.stencil(gen, u, lhs, 1.0, -1.0, -1.0, 0.0)       # (I - rL) u'
+    eng.stencil(gen, u0, rhs, 1.0, 1.0, 1.0, 2.0)        # (I + rL) u + 2 r S
+    assert float((lhs - rhs).abs().max() / rhs.abs().max()) < 1e-12
+    assert abs(float(u.sum() / u0.sum()) - 1.0) < 1e-12
+    assert float(u.min()) >= float(u0.min()) and float(u.max()) <= float(u0.max())
