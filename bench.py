@@ -9,6 +9,9 @@ Workloads (``--workload``):
                      one Peaceman-Rachford CN-ADI step (both sweeps).  This is the configuration the metric
                      and the >=40 %-of-HBM-roofline target of BASELINE.json are quoted on.
   adi<N>             same at N x N (e.g. adi8192 for the cache-cold point, adi1024).
+  cn<N>              the DEFAULT scheme of run_2d_crank_nicolson on the same N x N problem: one unsplit Crank-Nicolson step
+                     (what the reference's SuperLU solve computes) = right-hand side + Peaceman-Rachford cycle + residual
+                     check; `roofline` is the whole step against a transfer model, not one launch.
   c2                 1024 x 1024, NE=12, recombination on, phonons frozen: Strang C(dt/2) D(dt) C(dt/2) per step
                      (BASELINE configs[1]); cell-updates count NE diffusion updates per pixel per step.
   c3                 4096 x 4096, NE=12, recombination + scattering with dynamic phonons (BASELINE configs[2]).

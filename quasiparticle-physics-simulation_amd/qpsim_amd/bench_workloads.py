@@ -128,6 +128,49 @@ class ADIWorkload:
                 "note": "launch time = (event time of k-step calls) / (2k+1 sweep launches); includes the reduced-system kernels"}
 
 
+class ExactCNWorkload(ADIWorkload):
+    """The DEFAULT scheme of `run_2d_crank_nicolson` (unsplit Crank-Nicolson, what the reference's SuperLU solve computes,
+    `solver.py:231,1155-1161,1441`): one `Engine.cn_exact_step` per step on a full rectangle - right-hand side, one carried
+    Peaceman-Rachford cycle of J iterations, residual check."""
+
+    def __init__(self, N: int, device):
+        super().__init__(N, device)
+        self.description = (f"{N}x{N} fp64 unsplit Crank-Nicolson step (default scheme: Peaceman-Rachford cycle to "
+                            "rtol 1e-13 of the residual), 1 field, full rectangle, reflective walls, D=6 dt=0.1 dx=1")
+        self.path = "qp_adi_rect_combine + qp_adi_rect_pr_cycle (carried, fine tiles where the plans qualify) + residual check"
+        self.iterations = []
+
+    def run(self, k: int):
+        for _ in range(k):
+            self.iterations.append(self.eng.cn_exact_step(self.op, self.u))
+
+    run_steps = run
+
+    def roofline(self, nrep: int) -> dict:
+        """Plane transfers of one step by the cycle's own accounting (2 for the right-hand side, 6 J + 2 for the carried
+        cycle, 3 for the residual check) x 8 B x cells, over the measured step time."""
+        torch = self.eng.torch
+        self.run(2)
+        torch.cuda.synchronize(self.eng.device)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream(self.eng.device))
+        self.run(nrep)
+        ev1.record(torch.cuda.current_stream(self.eng.device))
+        torch.cuda.synchronize(self.eng.device)
+        per_step = ev0.elapsed_time(ev1) * 1e-3 / nrep
+        J = int(self.iterations[-1])
+        transfers = 2 + 6 * J + 2 + 3
+        moved = transfers * 8.0 * self.cell_updates_per_step
+        achieved = moved / per_step / 1e9
+        self.bytes_per_step = moved
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "traffic_source": None,
+                "kernel": "one exact-CN step: rect_combine_kernel x2, fine_y_kernel<0,SRC>, J x fine_x_kernel<SRC>, "
+                          "(J-1) x fine_y_next_kernel, fine_y_kernel<2>",
+                "bytes_per_launch": moved, "avg_launch_us": per_step * 1e6, "iterations_per_step": J,
+                "note": f"whole step, not one launch: {transfers} plane transfers of 8 B per cell (model) over the step time"}
+
+
 class CoupledWorkload:
     """Energy-resolved hot loop: external generation off, Strang C(dt/2) D(dt) C(dt/2), Pauli guard every step.
 
@@ -462,6 +505,9 @@ def build(name: str, device):
     m = re.fullmatch(r"adi(\d+)", name)
     if m:
         return ADIWorkload(int(m.group(1)), device)
+    m = re.fullmatch(r"cn(\d+)", name)
+    if m:   # cn<N>: the default scheme (unsplit CN) on an N x N rectangle
+        return ExactCNWorkload(int(m.group(1)), device)
     m = re.fullmatch(r"ring(\d+)(?:x(\d+))?", name)
     if m:   # ring<N>[x<F>]: annulus mask inside N x N (masked tiled path), F fields
         return ADIWorkload(int(m.group(1)), device, nfield=int(m.group(2) or 1), ring=True)
