@@ -513,6 +513,7 @@ struct qp_adi_rect_plan {
   double* d_iface[2] = {nullptr, nullptr};
   double* d_z[2] = {nullptr, nullptr};
   double* d_uhalo[2] = {nullptr, nullptr};
+  double* d_slab = nullptr;  // ONE device allocation behind every table / interface pointer above and below (SlabBuilder)
   double* d_work = nullptr;  // [nfield][ncell] carried right-hand side
   bool owns_work = true;     // false: d_work belongs to another plan (qp_adi_rect_plan_create_pr with `share`)
   double pr_scale = 0.0;     // != 0: Peaceman-Rachford iteration plan, 1 / (1/2 + p)
@@ -629,6 +630,48 @@ __global__ void __launch_bounds__(256) rect_combine_kernel(int ny, int nx, int n
 
 // Fine tiles are eligible on undecomposed grids whose extents are multiples of 64.  QPSIM_FINE_TILES=0 / 1 forces the
 // choice (1: whenever the plan qualifies); the default is the size rule measured on MI355X.
+// All small device arrays of a plan live in one allocation: a plan used to cost ~17 hipMalloc + as many blocking copies
+// (~3 ms), which showed when the host builds a Peaceman-Rachford cycle of 7-8 plans for a 200-step run on a 64^2 grid.
+// Uploads are staged in one host buffer and copied once; the zero-filled arrays follow and get one hipMemset.
+struct SlabBuilder {
+  struct Item {
+    double** dst;
+    size_t count;
+    const double* host;      // nullptr: zero-filled
+  };
+  std::vector<Item> items;
+  std::vector<std::vector<double>> owned;      // host arrays whose builders have returned
+  static size_t pad(size_t n) { return (n + 31) & ~(size_t)31; }      // 256-byte granules
+  void upload(const std::vector<double>& h, double** dst) { items.push_back({dst, h.size(), h.data()}); }
+  void upload_owned(std::vector<double>&& h, double** dst) {
+    owned.push_back(std::move(h));
+    items.push_back({dst, owned.back().size(), owned.back().data()});
+  }
+  void zeros(size_t count, double** dst) { items.push_back({dst, count, nullptr}); }
+  bool commit(double** slab) {
+    size_t up = 0, total = 0;
+    for (const Item& it : items) if (it.host) up += pad(it.count);
+    total = up;
+    for (const Item& it : items) if (!it.host) total += pad(it.count);
+    if (hipMalloc((void**)slab, std::max<size_t>(total, 32) * sizeof(double)) != hipSuccess) return false;
+    std::vector<double> stage(up, 0.0);
+    size_t o = 0, z = up;
+    for (const Item& it : items) {
+      if (it.host) {
+        std::copy(it.host, it.host + it.count, stage.begin() + o);
+        *it.dst = *slab + o;
+        o += pad(it.count);
+      } else {
+        *it.dst = *slab + z;
+        z += pad(it.count);
+      }
+    }
+    if (up && hipMemcpy(*slab, stage.data(), up * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return false;
+    if (total > up && hipMemset(*slab + up, 0, (total - up) * sizeof(double)) != hipSuccess) return false;
+    return true;
+  }
+};
+
 static bool fine_tiles_allowed() {      // QPSIM_FINE_TILES=0 switches the fine kernels off everywhere
   const char* e = getenv("QPSIM_FINE_TILES");
   return !e || atoi(e) != 0;
@@ -644,7 +687,8 @@ static bool fine_tiles_wanted(int nfield, int ny, int nx) {
 
 // Tables, interface coefficients and interface arrays of the fine view; leaves plan->fine false (and no error) when the
 // plan does not qualify: chunks of 32 cells not decoupled at this r D, or a table without the compact form.
-static int fine_plan_create(qp_adi_rect_plan* plan, double r, const double* dcoef_host, const DirSpec (&coarse)[2]) {
+static void fine_plan_prepare(qp_adi_rect_plan* plan, double r, const double* dcoef_host, const DirSpec (&coarse)[2],
+                              SlabBuilder& slab) {
   const RectView& v = plan->view;
   const int nfield = v.d.nfield, ny = v.d.ny, nx = v.d.nx;
   FineView& f = plan->fview;
@@ -681,38 +725,22 @@ static int fine_plan_create(qp_adi_rect_plan* plan, double r, const double* dcoe
           for (int k = 0; k < FS - 1; ++k) eav[k] = eav[k] * ev[k + 1] / ev[k];
           eav[FS - 1] = 0.0;
         }
-        if (!table_is_compact_len(FS, tab.data())) return QP_OK;
+        if (!table_is_compact_len(FS, tab.data())) return;
         build_compact_table_len(FS, tab.data(), &ctab[(((size_t)d * nfield + b) * 4 + var) * 2 * CT_PART]);
       }
       const double far = reduced_tables(spec[d], a, 0, P, nullptr, &icoef[d][(size_t)b * (P + 1) * 3], FS);
-      if (!(far < kFarCouplingDrop)) return QP_OK;
+      if (!(far < kFarCouplingDrop)) return;
     }
   }
-  bool ok = hipMalloc((void**)&plan->d_fctab, ctab.size() * sizeof(double)) == hipSuccess &&
-            hipMemcpy(plan->d_fctab, ctab.data(), ctab.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
-  for (int d = 0; d < 2 && ok; ++d) {
+  slab.upload_owned(std::move(ctab), &plan->d_fctab);
+  for (int d = 0; d < 2; ++d) {
     const size_t nlines = d == 0 ? ny : nx;
-    const size_t ni = (size_t)nfield * (2 * spec[d].P + 2) * nlines;
-    ok = hipMalloc((void**)&plan->d_ficoef[d], icoef[d].size() * sizeof(double)) == hipSuccess &&
-         hipMemcpy(plan->d_ficoef[d], icoef[d].data(), icoef[d].size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
-         hipMalloc((void**)&plan->d_fiface[d], ni * sizeof(double)) == hipSuccess &&
-         hipMemset(plan->d_fiface[d], 0, ni * sizeof(double)) == hipSuccess;
+    slab.upload_owned(std::move(icoef[d]), &plan->d_ficoef[d]);
+    slab.zeros((size_t)nfield * (2 * spec[d].P + 2) * nlines, &plan->d_fiface[d]);
   }
-  if (!ok) {
-    (void)hipGetLastError();
-    set_error("qp_adi_rect_plan_create: device allocation or upload failed (fine tiles)");
-    return QP_ERR_ALLOC;
-  }
-  f.alpha = plan->d_alpha;
   f.bsrc = nullptr;
   f.bscale = 0.0;
-  f.ctab = plan->d_fctab;
-  for (int d = 0; d < 2; ++d) {
-    f.icoef[d] = plan->d_ficoef[d];
-    f.iface[d] = plan->d_fiface[d];
-  }
-  plan->fine = true;
-  return QP_OK;
+  plan->fine = true;      // the view's pointers are bound after SlabBuilder::commit (rect_plan_create_impl)
 }
 
 // the passes of qp_adi_rect_phase on the fine view (interfaces always decoupled: the reduced phases are empty)
@@ -749,22 +777,8 @@ extern "C" {
 
 int qp_adi_rect_plan_destroy(qp_adi_rect_plan* plan) {
   if (!plan) return QP_OK;
-  (void)hipFree(plan->d_alpha);
-  (void)hipFree(plan->d_tab);
-  (void)hipFree(plan->d_ctab);
-  for (int d = 0; d < 2; ++d) {
-    (void)hipFree(plan->d_lu[d]);
-    (void)hipFree(plan->d_icoef[d]);
-    (void)hipFree(plan->d_iface[d]);
-    (void)hipFree(plan->d_z[d]);
-    (void)hipFree(plan->d_uhalo[d]);
-  }
+  (void)hipFree(plan->d_slab);      // every table / interface array
   if (plan->owns_work) (void)hipFree(plan->d_work);
-  (void)hipFree(plan->d_fctab);
-  for (int d = 0; d < 2; ++d) {
-    (void)hipFree(plan->d_ficoef[d]);
-    (void)hipFree(plan->d_fiface[d]);
-  }
   delete plan;
   return QP_OK;
 }
@@ -848,15 +862,10 @@ static int rect_plan_create_impl(int32_t ny, int32_t nx, int32_t nfield, double 
               far[0], far[1], kFarCouplingDrop);
     return QP_ERR_UNSUPPORTED;
   }
-  auto upload = [](const std::vector<double>& h, double** dptr) -> bool {
-    if (hipMalloc((void**)dptr, h.size() * sizeof(double)) != hipSuccess) return false;
-    return hipMemcpy(*dptr, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
-  };
-  auto zalloc = [](double** dptr, size_t count) -> bool {
-    if (hipMalloc((void**)dptr, count * sizeof(double)) != hipSuccess) return false;
-    return hipMemset(*dptr, 0, count * sizeof(double)) == hipSuccess;
-  };
-  bool ok = upload(alpha, &plan->d_alpha) && upload(tab, &plan->d_tab) && upload(ctab, &plan->d_ctab);
+  SlabBuilder slab;
+  slab.upload(alpha, &plan->d_alpha);
+  slab.upload(tab, &plan->d_tab);
+  slab.upload(ctab, &plan->d_ctab);
   v.compact = all_compact ? 1 : 0;
   if (const char* e = getenv("QPSIM_COMPACT_TABLES")) v.compact = v.compact && atoi(e) != 0;   // 0: force the full form
   v.bsrc = nullptr;
@@ -864,22 +873,19 @@ static int rect_plan_create_impl(int32_t ny, int32_t nx, int32_t nfield, double 
   plan->pr_scale = pr_scale;
   // fine tiles first: a plan that runs them needs no interface arrays for the 64 x 64 kernels when it is the plan of a
   // Peaceman-Rachford iteration (nothing else ever runs on it)
-  if (ok && !decomposed && force_banded == 0 && ny % 64 == 0 && nx % 64 == 0 &&
-      (pr_scale != 0.0 ? fine_tiles_allowed() : fine_tiles_wanted(nfield, ny, nx))) {
-    const int rc = fine_plan_create(plan, r, dcoef_host, spec);
-    if (rc != QP_OK) {
-      qp_adi_rect_plan_destroy(plan);
-      return rc;
-    }
-  }
+  if (!decomposed && force_banded == 0 && ny % 64 == 0 && nx % 64 == 0 &&
+      (pr_scale != 0.0 ? fine_tiles_allowed() : fine_tiles_wanted(nfield, ny, nx)))
+    fine_plan_prepare(plan, r, dcoef_host, spec, slab);
   const bool lean = pr_scale != 0.0 && plan->fine;
-  for (int d = 0; d < 2 && ok; ++d) {
+  for (int d = 0; d < 2; ++d) {
     const size_t nlines = d == 0 ? ny : nx;
-    ok = upload(lu[d], &plan->d_lu[d]) && upload(icoef[d], &plan->d_icoef[d]) &&
-         zalloc(&plan->d_iface[d], lean ? 1 : (size_t)nfield * (2 * ploc[d] + 2) * nlines) &&
-         zalloc(&plan->d_z[d], lean ? 1 : (size_t)nfield * 2 * ploc[d] * nlines) &&
-         zalloc(&plan->d_uhalo[d], lean ? 1 : (size_t)nfield * nx);
+    slab.upload(lu[d], &plan->d_lu[d]);
+    slab.upload(icoef[d], &plan->d_icoef[d]);
+    slab.zeros(lean ? 1 : (size_t)nfield * (2 * ploc[d] + 2) * nlines, &plan->d_iface[d]);
+    slab.zeros(lean ? 1 : (size_t)nfield * 2 * ploc[d] * nlines, &plan->d_z[d]);
+    slab.zeros(lean ? 1 : (size_t)nfield * nx, &plan->d_uhalo[d]);
   }
+  bool ok = slab.commit(&plan->d_slab);
   if (share) {
     plan->d_work = share->d_work;
     plan->owns_work = false;
@@ -901,6 +907,15 @@ static int rect_plan_create_impl(int32_t ny, int32_t nx, int32_t nfield, double 
     v.iface[d] = plan->d_iface[d];
     v.z[d] = plan->d_z[d];
     v.uhalo[d] = plan->d_uhalo[d];
+  }
+  if (plan->fine) {
+    FineView& f = plan->fview;
+    f.alpha = plan->d_alpha;
+    f.ctab = plan->d_fctab;
+    for (int d = 0; d < 2; ++d) {
+      f.icoef[d] = plan->d_ficoef[d];
+      f.iface[d] = plan->d_fiface[d];
+    }
   }
   *out = plan;
   return QP_OK;

@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes as C
 from dataclasses import dataclass
 
+import math
 import os
 
 import numpy as np
@@ -263,32 +264,46 @@ class RectPlan:
             pass
 
 
-def peaceman_rachford_parameters(alpha: float, beta: float, reduction: float, jmax: int = 24):
-    """Cyclic iteration parameters p_1..p_J for commuting H, V with spectra in [alpha, beta]: one cycle multiplies every
-    error component by prod_j ((h - p_j)/(h + p_j)) ((v - p_j)/(v + p_j)).  Jordan's optimal parameters
-    p_j = beta dn((2j-1) K / (2J), k), k^2 = 1 - (alpha/beta)^2 when SciPy's elliptic functions are importable, the
-    geometric sequence otherwise; the smallest J whose worst-case factor (evaluated on 4000 points of the interval)
-    is <= ``reduction``.  Returns (parameters, worst-case factor)."""
+def _jacobi_dn(u: float, m: float) -> tuple[float, float]:
+    """(dn(u | m), K(m)) by the arithmetic-geometric mean (Abramowitz & Stegun 16.4, 17.6), parameter m = k^2 < 1."""
+    a, b, c = [1.0], [math.sqrt(1.0 - m)], [math.sqrt(m)]
+    while abs(c[-1]) > 1e-17 and len(a) < 40:
+        a.append(0.5 * (a[-1] + b[-1]))
+        b.append(math.sqrt(a[-2] * b[-1]))
+        c.append(0.5 * (a[-2] - b[-2]))
+    n = len(a) - 1
+    K = math.pi / (2.0 * a[n])
+    phi = [0.0] * (n + 1)
+    phi[n] = (2.0 ** n) * a[n] * u
+    for k in range(n, 0, -1):
+        phi[k - 1] = 0.5 * (phi[k] + math.asin(c[k] * math.sin(phi[k]) / a[k]))
+    if n == 0:
+        return 1.0, K
+    return math.cos(phi[0]) / math.cos(phi[1] - phi[0]), K
+
+
+def peaceman_rachford_cycle(alpha: float, beta: float, J: int):
+    """Jordan's optimal cyclic parameters of J Peaceman-Rachford iterations for commuting H, V with spectra in
+    [alpha, beta], p_j = beta dn((2j-1) K / (2J), k), k^2 = 1 - (alpha/beta)^2, and the worst-case factor
+    max_{h,v} prod_j |(h - p_j)/(h + p_j)| |(v - p_j)/(v + p_j)| of the cycle (evaluated on 4000 points of the interval)."""
     alpha, beta = float(alpha), float(max(beta, alpha * (1.0 + 1e-9)))
+    m = 1.0 - (alpha / beta) ** 2
+    K = _jacobi_dn(0.0, m)[1]
+    ps = [beta * _jacobi_dn((2 * j - 1) * K / (2.0 * J), m)[0] for j in range(1, J + 1)]
     h = np.geomspace(alpha, beta, 4000)
-    try:
-        from scipy.special import ellipj, ellipk
-    except ImportError:      # pragma: no cover - SciPy is an optional accelerator here
-        ellipj = ellipk = None
+    f = np.ones_like(h)
+    for p in ps:
+        f *= np.abs((h - p) / (h + p))
+    return ps, float(f.max()) ** 2
+
+
+def peaceman_rachford_parameters(alpha: float, beta: float, reduction: float, jmax: int = 24):
+    """The shortest cycle (``peaceman_rachford_cycle``) whose worst-case factor is <= ``reduction`` (or the cycle of
+    ``jmax`` iterations when none is).  Returns (parameters, worst-case factor)."""
     best = None
     for J in range(1, jmax + 1):
-        if ellipj is not None:
-            m = 1.0 - (alpha / beta) ** 2
-            K = ellipk(m)
-            ps = [beta * float(ellipj((2 * j - 1) * K / (2 * J), m)[2]) for j in range(1, J + 1)]
-        else:
-            ps = [alpha * (beta / alpha) ** ((2 * j - 1) / (2.0 * J)) for j in range(1, J + 1)]
-        f = np.ones_like(h)
-        for p in ps:
-            f *= np.abs((h - p) / (h + p))
-        worst = float(f.max()) ** 2
-        best = (ps, worst)
-        if worst <= reduction:
+        best = peaceman_rachford_cycle(alpha, beta, J)
+        if best[1] <= reduction:
             break
     return best
 
@@ -377,38 +392,50 @@ class DiffusionOperator:
                     self.tile_refused = str(exc)
 
 
-def _pr_cycle(op: "DiffusionOperator", reduction: float):
-    """Peaceman-Rachford plans of ``op`` for a worst-case error reduction ``reduction`` per cycle (cached), or None when the
-    operator does not qualify: not a full rectangle with one D per field and one BC per side (Lx, Ly would not commute),
-    or a boundary diagonal term below zero (H, V no longer bounded below by 1/2)."""
-    key = float(reduction)
-    if key in op._pr_cycles:
-        return op._pr_cycles[key]
+def _pr_bounds(op: "DiffusionOperator"):
+    """(alpha, beta) holding the spectra of H = I/2 - r D Lx and V = I/2 - r D Ly of ``op``, or None when the operator has no
+    Peaceman-Rachford cycle: not a full rectangle with one D per field and one BC per side (Lx, Ly would not commute), or a
+    boundary diagonal term below zero (H, V no longer bounded below by 1/2)."""
+    if (op.rect is None or op._sides is None or min(op._sides[0]) < 0.0 or os.environ.get("QPSIM_CN_PR", "1") == "0"):
+        return None
+    amax = op.r * float(op.dcoef.max().item())
+    if amax <= 0.0:
+        return None
+    emax = max(op._sides[0])
+    return 0.5, 0.5 + amax * max(4.0, 2.0 + emax, 2.0 * emax)      # Gershgorin; 2 e: a direction one cell thick
+
+
+def _pr_cycle(op: "DiffusionOperator", J: int):
+    """The plans of the J-iteration Peaceman-Rachford cycle of ``op`` (cached, at most four cycles), or None."""
+    if J in op._pr_cycles:
+        return op._pr_cycles[J]
     cycle = None
+    bounds = _pr_bounds(op)
     eng = op.engine
-    if (op.rect is not None and op._sides is not None and min(op._sides[0]) >= 0.0
-            and os.environ.get("QPSIM_CN_PR", "1") != "0"):
+    if bounds is not None:
+        ps, _ = peaceman_rachford_cycle(bounds[0], bounds[1], int(J))
         dc = op.dcoef.cpu().numpy()
-        amax = op.r * float(dc.max())
-        if amax > 0.0:
-            emax = max(op._sides[0])
-            beta = 0.5 + amax * max(4.0, 2.0 + emax, 2.0 * emax)      # Gershgorin; 2 e: a direction one cell thick
-            ps, worst = peaceman_rachford_parameters(0.5, beta, reduction)
-            if worst <= reduction:
-                try:
-                    with eng.torch.cuda.device(eng.device):
-                        plans = []
-                        for p in ps:
-                            plans.append(RectPlan.peaceman_rachford(eng.lib, eng.ny, eng.nx, op.nfield, op.r, dc,
-                                                                    op._sides[0], p, share=plans[0] if plans else None))
-                    cycle = plans
-                except _hip.QPHipError as exc:
-                    if exc.status != -3:      # QP_ERR_UNSUPPORTED
-                        raise
-    while len(op._pr_cycles) >= 2:      # the adaptive cycle length moves between neighbouring targets: keep two sets of plans
+        try:
+            with eng.torch.cuda.device(eng.device):
+                plans = []
+                for p in ps:
+                    plans.append(RectPlan.peaceman_rachford(eng.lib, eng.ny, eng.nx, op.nfield, op.r, dc, op._sides[0], p,
+                                                            share=plans[0] if plans else None))
+            cycle = plans
+        except _hip.QPHipError as exc:
+            if exc.status != -3:      # QP_ERR_UNSUPPORTED
+                raise
+    while len(op._pr_cycles) >= 4:      # the cycle length moves one iteration at a time: a few neighbouring lengths stay built
         op._pr_cycles.pop(next(iter(op._pr_cycles)))
-    op._pr_cycles[key] = cycle
+    op._pr_cycles[J] = cycle
     return cycle
+
+
+def _pr_initial_length(op: "DiffusionOperator", reduction: float):
+    bounds = _pr_bounds(op)
+    if bounds is None:
+        return None
+    return len(peaceman_rachford_parameters(bounds[0], bounds[1], reduction)[0])
 
 
 class FrameTicket:
@@ -645,11 +672,17 @@ class Engine:
         # spectrum of I/2 - r D L_dir - 8 plane transfers per iteration against 13 of the preconditioned iteration below and
         # a larger reduction per iteration (r D = 0.3: x45 against x11).  The residual is checked afterwards; whatever is
         # left (worst-case bound missed, e.g. rounding at very small rtol) is polished by the iteration below.
-        # The cycle length follows the data: the worst-case reduction asked of a cycle starts at 100 rtol (the old field is
-        # an O(r D) guess) and is relaxed by a factor 30 whenever a cycle ended a hundred times below the tolerance, tightened
-        # again when one missed it (smooth physical fields need 5-6 iterations where random data needs 8 at r D = 0.3).
-        target = getattr(op, "_pr_target", max(100.0 * rtol, 1e-15))
-        cycle = _pr_cycle(op, target) if rho > self.CHEBYSHEV_FROM else None
+        # The cycle length follows the data.  It starts at the length whose worst-case factor is 100 rtol (the old field is
+        # an O(r D) guess), drops by one iteration whenever a cycle ended 30 times below the tolerance (smooth physical
+        # fields need 5-6 iterations where random data needs 8 at r D = 0.3) and grows by one when a cycle missed it -
+        # after which shorter cycles are not tried again for 8, 16, 32 ... steps (doubling with every miss).
+        J = None
+        if rho > self.CHEBYSHEV_FROM:
+            J = getattr(op, "_pr_J", None)
+            if J is None:
+                J = op._pr_J = _pr_initial_length(op, max(100.0 * rtol, 1e-15))
+                op._pr_hold, op._pr_backoff = 0, 8
+        cycle = _pr_cycle(op, J) if J is not None else None
         if cycle is not None:
             # in place on u (the right-hand side R is already formed): no copies when the cycle suffices
             handles = (C.POINTER(_hip.RectPlan) * len(cycle))(*[plan.handle for plan in cycle])
@@ -660,10 +693,13 @@ class Engine:
             if not np.isfinite(err):
                 raise FloatingPointError("exact-CN iteration diverged (non-finite residual)")
             if err <= rtol * scale:
-                if err <= 0.01 * rtol * scale and target < 1e-3:
-                    op._pr_target = target * 30.0
+                if op._pr_hold > 0:
+                    op._pr_hold -= 1
+                elif err <= rtol * scale / 30.0 and J > 2:
+                    op._pr_J = J - 1
                 return len(cycle)
-            op._pr_target = max(target / 30.0, 1e-15)
+            op._pr_J, op._pr_hold = min(J + 1, 24), op._pr_backoff
+            op._pr_backoff = min(2 * op._pr_backoff, 512)
             v.copy_(u)
         else:
             v.copy_(u)

@@ -37,5 +37,5 @@ for arg in sys.argv[1:]:
     ev1.record()
     torch.cuda.synchronize()
     ms = ev0.elapsed_time(ev1) / 20
-    print(f"{arg}: exact-CN step {ms:.3f} ms, iterations {its[-5:]}, rho bound {eng.cn_contraction_bound(op):.3f}; "
+    print(f"{arg}: exact-CN step {ms:.3f} ms, iterations {its}, rho bound {eng.cn_contraction_bound(op):.3f}; "
           f"{N * N / ms * 1e3:.3e} cell-updates/s", flush=True)
