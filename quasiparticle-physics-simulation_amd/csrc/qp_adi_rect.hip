@@ -197,6 +197,10 @@ __global__ void __launch_bounds__(64) QP_WAVES_ATTR rect_x_kernel(RectView v, do
   const auto cy = coef_source<COMPACT, T_EW, T_NSLOT - T_EW>(v, 1, t.b, vary, lane);
   double e[TS];
   load_cols(plane, t, v.d.nx, lane, e);
+  if constexpr (COMPACT) {
+    const CoefCompact parts[2] = {cx, cy};
+    warm_scalar_cache(parts);
+  }
   transpose64(e, lds, lane);
   double gl, gr;
   ghost_finish<0>(v, t.b, t.tx, row_on, graw, gl, gr);
@@ -253,6 +257,15 @@ __global__ void __launch_bounds__(64) QP_WAVES_ATTR rect_y_kernel(RectView v, co
   }
   double e[TS];
   load_cols(splane, t, v.d.nx, lane, e);
+  if constexpr (COMPACT) {
+    if (MODE == 2) {
+      const CoefCompact parts[1] = {cy};
+      warm_scalar_cache(parts);
+    } else {
+      const CoefCompact parts[2] = {cy, cx};
+      warm_scalar_cache(parts);
+    }
+  }
   if (MODE == 1 || MODE == 2) {
     ghost_finish<1>(v, t.b, t.ty, col_on, graw, gu, gd);
     e[0] = fma(a, gu, e[0]);

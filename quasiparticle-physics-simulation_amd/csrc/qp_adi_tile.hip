@@ -397,6 +397,10 @@ __device__ __forceinline__ void tile_x_body(const TileView& v, double* __restric
   const auto cends = clean_coefs<COMPACT, 1>(v, t.b, lane, CLS == 0);
   double e[TS];
   load_cols(plane, t, v.nx, lane, e);
+  if constexpr (COMPACT && CLS == 0) {
+    const CoefCompact parts[2] = {csolve, cends};
+    warm_scalar_cache(parts);
+  }
   transpose64(e, lds, lane);
   double gl, gr;
   tile_ghosts_finish<0>(v, t.tx, lane < t.nr, graw, gl, gr);
@@ -471,6 +475,10 @@ __device__ __forceinline__ void tile_y_body(const TileView& v, const double* src
   }
   double e[TS];
   load_cols(splane, t, v.nx, lane, e);
+  if constexpr (COMPACT && CLS == 0) {
+    const CoefCompact parts[2] = {csolve, cends};
+    warm_scalar_cache(parts);
+  }
   if (MODE == 1 || MODE == 2) tile_ghosts_finish<1>(v, t.ty, col_on, graw, gu, gd);
   if (CLS != 0) {
     if (MODE == 0) line_work<CLS, 1, false, true>(v, t, lane, has_bc, bct, a, e, gu, gd);
