@@ -86,7 +86,7 @@ class ADIWorkload:
         k = json.loads((prof / name).read_text())["kernels"]
         pick = lambda frag: sum(v["hbm_bytes_per_launch"] for n_, v in k.items() if frag in n_)  # noqa: E731
         if self.op.rect is not None and self.op.rect.fine:
-            val = 0.5 * (pick("fine_x_kernel<true, 0>") + pick("fine_y_kernel<1, 0>"))
+            val = 0.5 * (pick("fine_x_kernel<true, 0, false>") + pick("fine_y_kernel<1, 0, false>"))
         elif self.op.rect is not None:
             val = 0.5 * (pick("rect_x_kernel<true, 0, true>") + pick("rect_y_kernel<1, 0, true>"))
         elif self.op.tile is not None:      # one sweep = one merged launch (clean + general tiles); mean of x and carried y
