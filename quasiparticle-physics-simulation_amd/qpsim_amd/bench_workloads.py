@@ -461,6 +461,7 @@ class OverlapDecomposedWorkload:
         self.path = (f"overlapped-halo decomposition {py}x{px}: block {ny}x{nx} + halo {b.halo} = {b.ey}x{b.ex} per rank "
                      f"(+{100 * self.halo_overhead:.1f} % cells), halo refresh every {b.steps_per_exchange} steps "
                      f"(x strips then y strips, point-to-point over RCCL), rect-tiled partition ADI"
+                     + (", fine tiles (32-cell chunks)" if b.plan.fine else "")
                      + (" + register collision kernel" if coupled else ""))
         self.description = (f"{N}x{N} fp64 " + ("coupled step C(dt/2) D(dt) C(dt/2), NE=12, " if coupled else "CN-ADI step, ")
                             + f"domain-decomposed {py}x{px} (one block per GPU), reflective walls, D=6 dt=0.1 dx=1")
