@@ -227,8 +227,28 @@ def ensemble_record(args, dev, world: int) -> dict:
             "ms_per_step": 1e3 * elapsed / steps, "pixel_steps_per_s": wl.npix * world * steps / elapsed}
 
 
+_RESULT_FD = None
+
+
+def _claim_stdout() -> None:
+    """Keep stdout for the ONE JSON line: file descriptor 1 is pointed at stderr for everything else.  RCCL prints a
+    version banner ("HIP version : ...", "Librccl path : ...") to stdout when a communicator is created, gloo its
+    connection summary - with N ranks that is 4 N lines in front of the result."""
+    global _RESULT_FD
+    sys.stdout.flush()
+    _RESULT_FD = os.dup(1)
+    os.dup2(2, 1)
+
+
+def _emit(result: dict) -> None:
+    line = (json.dumps(result) + "\n").encode()
+    sys.stdout.flush()
+    os.write(_RESULT_FD if _RESULT_FD is not None else 1, line)
+
+
 def main():
     args = parse_args()
+    _claim_stdout()
     import torch
     import torch.distributed as dist
 
@@ -291,7 +311,7 @@ def main():
                 printed.set()
                 for key in ("strong", "ensemble"):
                     result.setdefault(key, {"error": f"not finished within {args.subrecord_timeout:.0f} s"})
-                print(json.dumps(result), flush=True)
+                _emit(result)
             os._exit(0)
 
         timer = threading.Timer(args.subrecord_timeout + (0.0 if rank == 0 else 5.0), watchdog)
@@ -309,7 +329,7 @@ def main():
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0 would hold the others up)
             result["cpu_baseline"] = cpu_baseline(args, args.workload)
-        print(json.dumps(result), flush=True)
+        _emit(result)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
