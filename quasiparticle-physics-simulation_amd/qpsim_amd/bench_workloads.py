@@ -461,7 +461,7 @@ class OverlapDecomposedWorkload:
         self.path = (f"overlapped-halo decomposition {py}x{px}: block {ny}x{nx} + halo {b.halo} = {b.ey}x{b.ex} per rank "
                      f"(+{100 * self.halo_overhead:.1f} % cells), halo refresh every {b.steps_per_exchange} steps "
                      f"(x strips then y strips, point-to-point over RCCL), rect-tiled partition ADI"
-                     + (", fine tiles (32-cell chunks)" if b.plan.fine else "")
+                     + (", fine tiles (32-cell chunks)" if getattr(getattr(b, "plan", None), "fine", False) else "")
                      + (" + register collision kernel" if coupled else ""))
         self.description = (f"{N}x{N} fp64 " + ("coupled step C(dt/2) D(dt) C(dt/2), NE=12, " if coupled else "CN-ADI step, ")
                             + f"domain-decomposed {py}x{px} (one block per GPU), reflective walls, D=6 dt=0.1 dx=1")
@@ -490,7 +490,8 @@ class OverlapDecomposedWorkload:
         achieved = bytes_per_launch / per_sweep / 1e9
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
-                "kernel": ("fine_x_kernel / fine_y_kernel" if self.block.plan.fine else "rect_x_kernel / rect_y_kernel")
+                "kernel": ("fine_x_kernel / fine_y_kernel" if getattr(getattr(self.block, "plan", None), "fine", False)
+                           else "rect_x_kernel / rect_y_kernel")
                 + " on the extended local block (rank 0)",
                 "bytes_per_launch": bytes_per_launch, "avg_launch_us": per_sweep * 1e6,
                 "note": "per-rank sweep on block + halos; the halo cells are redundant work and are NOT counted in `value`"}
