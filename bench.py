@@ -65,7 +65,10 @@ def parse_args():
                     help="emit the sub-records with one rank too (with --force-dist: rehearsal of the N > 1 code path)")
     ap.add_argument("--strong-size", type=int, default=8192, help="grid edge of the strong-scaling sub-record")
     ap.add_argument("--subrecord-timeout", type=float, default=420.0,
-                    help="seconds after which unfinished N > 1 sub-records are reported as errors and the line printed")
+                    help="seconds after which unfinished N > 1 sub-records are reported as errors, the line printed and "
+                         "every rank exits with status 3")
+    ap.add_argument("--sustained-seconds", type=float, default=0.5,
+                    help="pre-spin and window length of the `sustained` sub-record (0 disables it)")
     return ap.parse_args()
 
 
@@ -178,13 +181,45 @@ def timed_steps(wl, steps: int, dev, use_dist: bool, **run_kw) -> float:
     return elapsed
 
 
-def strong_scaling_record(args, dev, world: int, rank: int) -> dict:
+def sustained_record(args, wl, dev, use_dist: bool, world: int, ms_per_step_hint: float) -> dict:
+    """The same steps in the sustained-clock regime: >= `--sustained-seconds` of them as pre-spin, then a timed window of
+    the same length.  The headline window (`--steps` steps right after warm-up) lasts a few milliseconds on the ADI
+    workloads and starts from an idle chip; this record is the rate a long time loop sees."""
+    target = max(args.sustained_seconds, 0.0)
+    n = int(min(max(args.steps, np.ceil(1e3 * target / max(ms_per_step_hint, 1e-6))), 50000))
+    t0 = time.perf_counter()
+    spun = 0
+    while time.perf_counter() - t0 < target:       # pre-spin: whole calls of n steps until the time is up
+        wl.run(n)
+        import torch
+        torch.cuda.synchronize(dev)
+        spun += n
+    elapsed = timed_steps(wl, n, dev, use_dist)
+    rec = {"steps": n, "prespin_steps": spun, "prespin_s": time.perf_counter() - t0 - elapsed, "window_s": elapsed,
+           "ms_per_step": 1e3 * elapsed / n, "value": wl.cell_updates_per_step * world * n / elapsed,
+           "unit": "cell-updates/s",
+           "hbm_frac_of_step": (wl.bytes_per_step * n / elapsed / 1e9) / HBM_PEAK_GBS}
+    if hasattr(wl, "sweep_launches"):
+        sweeps = wl.sweep_launches(n)
+        rec["sweep_us"] = 1e6 * elapsed / sweeps
+        rec["sweep_hbm_frac"] = (16.0 * wl.cell_updates_per_step / (elapsed / sweeps) / 1e9) / HBM_PEAK_GBS
+        rec["note"] = "sweep_us = window / (2 steps + 1) tile-sweep launches of the one library call"
+    return rec
+
+
+def strong_scaling_record(args, dev, world: int, rank: int, stage: dict | None = None) -> dict:
     """north_star's strong-scaling figure, measured in this run: the SAME N x N problem (default 8192^2, BASELINE configs[4])
     first on rank 0 alone (the other ranks wait at the barrier), then decomposed over all ranks."""
     import torch
     import torch.distributed as dist
     from qpsim_amd import bench_workloads as W
     N = args.strong_size
+    stage = {} if stage is None else stage
+
+    def at(name: str) -> None:
+        stage["name"] = f"strong: {name}"
+
+    at("1-rank reference run on rank 0")
     t1 = torch.zeros(1, dtype=torch.float64, device=dev)
     if rank == 0:
         single = W.ADIWorkload(N, dev)
@@ -196,12 +231,59 @@ def strong_scaling_record(args, dev, world: int, rank: int) -> dict:
         t1[0] = time.perf_counter() - t0
         del single
         torch.cuda.empty_cache()
+    at("all_reduce(1-rank time)")
     dist.all_reduce(t1, op=dist.ReduceOp.MAX)        # everybody learns the 1-rank time (and waits for it)
     one_rank = float(t1.item())
-    wl = W.OverlapDecomposedWorkload(N, dev)
+    # Halo width: wider halos cost cells every step and save refreshes (S = 19 steps at 64 cells, 64 at 128 for r D = 0.3).
+    # Both candidates are built and MEASURED here - step time with the refreshes skipped, and the stages of a refresh -
+    # and the one with the smaller time per step runs the timed region (QPSIM_DD_HALO forces one).
+    from qpsim_amd.distributed import measure_refresh
+    forced = os.environ.get("QPSIM_DD_HALO")
+    table, built = {}, {}
+    for H in ([int(forced)] if forced else [64, 128]):
+        at(f"halo {H}: plan")
+        cand, why = None, ""
+        try:
+            cand = W.OverlapDecomposedWorkload(N, dev, halo=H)
+        except ValueError as exc:          # blocks smaller than the halo, or the step too stiff for it
+            why = str(exc)
+        fits = torch.tensor([1.0 if cand is not None else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(fits, op=dist.ReduceOp.MIN)          # a width is a candidate only if it fits on EVERY rank
+        if float(fits.item()) < 1.0:
+            table[H] = {"error": why or "does not fit on another rank"}
+            del cand
+            continue
+        spe = cand.block.steps_per_exchange
+        at(f"halo {H}: warm-up incl. first halo refresh (send/recv connections)")
+        cand.run(max(args.warmup, spe + 1))
+        k = max(5, min(args.steps, 20))
+        at(f"halo {H}: timed steps without refreshes")
+        step_us = 1e6 * timed_steps(cand, k, dev, True, exchange=False) / k
+        at(f"halo {H}: refresh stages (pack, isend/irecv batch, unpack)")
+        if world > 1:
+            st = measure_refresh(cand.block, cand.transport, reps=5, sync=lambda: torch.cuda.synchronize(dev))
+        else:
+            st = {"pack_us": 0.0, "exchange_us": 0.0, "unpack_us": 0.0, "refresh_us": 0.0, "bytes_received": 0}
+        vec = torch.tensor([st["pack_us"], st["exchange_us"], st["unpack_us"], st["refresh_us"]], dtype=torch.float64,
+                           device=dev)
+        dist.all_reduce(vec, op=dist.ReduceOp.MAX)          # every rank sees the same numbers and makes the same choice
+        pack_us, exchange_us, unpack_us, refresh_us = (float(v) for v in vec.tolist())
+        table[H] = {"steps_per_refresh": spe, "step_us": step_us, "pack_us": pack_us, "exchange_us": exchange_us,
+                    "unpack_us": unpack_us, "refresh_us": refresh_us, "us_per_step_model": step_us + refresh_us / max(spe, 1),
+                    "bytes_received_per_refresh": st["bytes_received"], "halo_cells_overhead": cand.halo_overhead}
+        built[H] = cand
+    if not built:
+        raise RuntimeError(f"no halo width fits: {table}")
+    choice = min(built, key=lambda h: table[h]["us_per_step_model"])
+    wl = built[choice]
+    for h in list(built):
+        if h != choice:
+            del built[h]
+    torch.cuda.empty_cache()
     spe = wl.block.steps_per_exchange
-    wl.run(max(args.warmup, spe + 1))                 # the warm-up includes at least one halo refresh (RCCL connections)
+    at("timed steps with halo refreshes (isend/irecv + barrier)")
     elapsed = timed_steps(wl, args.steps, dev, True)
+    at("timed steps without halo refreshes")
     no_xchg = timed_steps(wl, args.steps, dev, True, exchange=False)      # same kernels, refreshes skipped: timing only
     return {
         "workload": wl.description, "path": wl.path, "scaling": "strong", "rccl_ranks": dist.get_world_size(),
@@ -209,18 +291,26 @@ def strong_scaling_record(args, dev, world: int, rank: int) -> dict:
         "value": float(N) * N * args.steps / elapsed, "unit": "cell-updates/s", "ms_per_step": 1e3 * elapsed / args.steps,
         "one_rank_ms_per_step": 1e3 * one_rank / args.steps, "speedup_vs_one_rank": one_rank / elapsed,
         "exchange_share_of_time": max(0.0, 1.0 - no_xchg / elapsed), "steps_per_halo_refresh": spe,
+        "refresh_rounds": 1, "halo": choice, "halo_candidates": table,
+        "pack_us": table[choice]["pack_us"], "exchange_us": table[choice]["exchange_us"],
+        "unpack_us": table[choice]["unpack_us"], "refresh_us": table[choice]["refresh_us"],
         "halo_cells_overhead": wl.halo_overhead,
         "hbm_frac_of_step_per_gpu": (32.0 * N * N / world * args.steps / elapsed / 1e9) / HBM_PEAK_GBS,
+        "note": "one refresh = pack kernel + ONE batch of point-to-point messages (sides and corners) + unpack kernel; "
+                "the stage times are host wall-clock with a device synchronisation after each stage (max over ranks)",
     }
 
 
-def ensemble_record(args, dev, world: int) -> dict:
+def ensemble_record(args, dev, world: int, stage: dict | None = None) -> dict:
     """BASELINE configs[3]: ensemble of independent 256^2 MKID pixels, NE = 12 full physics, 64 members per GPU
     (512 at 8 GPUs), members never communicate."""
     from qpsim_amd import bench_workloads as W
+    stage = {} if stage is None else stage
+    stage["name"] = "ensemble: setup + warm-up"
     wl = W.build("c4", dev)
     wl.run(max(1, min(args.warmup, 5)))
     steps = max(1, min(args.steps, 50))
+    stage["name"] = "ensemble: timed steps (barrier + all_reduce of the time)"
     elapsed = timed_steps(wl, steps, dev, True)
     return {"workload": wl.description, "scaling": "weak", "members_total": 64 * world,
             "value": wl.cell_updates_per_step * world * steps / elapsed, "unit": "cell-updates/s", "steps": steps,
@@ -270,7 +360,14 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     dev = torch.device("cuda", device_index)
 
+    from qpsim_amd import _hip
     from qpsim_amd import bench_workloads as W
+
+    build = _hip.build_info()
+    if build.get("qp_abl", 0) != 0:
+        sys.stderr.write(f"bench.py: {build['library']} is a timing-only ablation build (QP_ABL={build['qp_abl']}); its "
+                         "results are wrong by construction - refusing to measure it\n")
+        sys.exit(4)
 
     wl = W.build(args.workload, dev)
     if args.warmup > 0:
@@ -294,7 +391,10 @@ def main():
                    "path": wl.path},
         "roofline": roof,
         "hbm_frac_of_step": (wl.bytes_per_step * args.steps / elapsed / 1e9) / HBM_PEAK_GBS,
+        "build": build,
     }
+    if args.sustained_seconds > 0:
+        result["sustained"] = sustained_record(args, wl, dev, use_dist, world, 1e3 * elapsed / args.steps)
     if hasattr(wl, "coll_bytes_per_call"):
         result["pixel_steps_per_s"] = wl.npix * world * args.steps / elapsed
     del wl
@@ -305,27 +405,50 @@ def main():
         # one becomes its "error" field, and if a rank gets stuck in them (a peer died, a collective that never returns)
         # every rank's watchdog ends its process after `--subrecord-timeout` seconds, rank 0 printing the line first.
         printed = threading.Event()
+        stage = {"name": "start"}
 
         def watchdog():
+            # A hung process that has touched the GPU must not be reported as success: the headline line is printed (it is
+            # complete), the pending stage goes to stderr, and every rank leaves with status 3.
+            sys.stderr.write(f"bench.py rank {rank}: sub-records not finished within {args.subrecord_timeout:.0f} s, "
+                             f"pending stage: {stage['name']}; exiting with status 3\n")
+            sys.stderr.flush()
             if rank == 0 and not printed.is_set():
                 printed.set()
                 for key in ("strong", "ensemble"):
-                    result.setdefault(key, {"error": f"not finished within {args.subrecord_timeout:.0f} s"})
+                    result.setdefault(key, {"error": f"not finished within {args.subrecord_timeout:.0f} s "
+                                                     f"(pending stage: {stage['name']})"})
                 _emit(result)
-            os._exit(0)
+            os._exit(3)
 
         timer = threading.Timer(args.subrecord_timeout + (0.0 if rank == 0 else 5.0), watchdog)
         timer.daemon = True
         timer.start()
-        for key, fn in (("strong", lambda: strong_scaling_record(args, dev, world, rank)),
-                        ("ensemble", lambda: ensemble_record(args, dev, world))):
+        failed = False
+        for key, fn in (("strong", lambda: strong_scaling_record(args, dev, world, rank, stage)),
+                        ("ensemble", lambda: ensemble_record(args, dev, world, stage))):
+            if failed:        # a rank that left a record early is out of step with its peers' collectives: stop here
+                result[key] = {"error": "skipped: an earlier sub-record failed on some rank"}
+                continue
+            stage["name"] = f"{key}: setup"
             try:
                 result[key] = fn()
+                ok = 1.0
             except Exception as exc:      # noqa: BLE001 - reported in the line, the headline stays valid
                 result[key] = {"error": f"{type(exc).__name__}: {exc}"}
+                ok = 0.0
+            # every rank learns whether ALL ranks finished this record; a failure anywhere marks the record on rank 0 too
+            stage["name"] = f"{key}: all_reduce(ok)"
+            flag = torch.tensor([ok], dtype=torch.float64, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag.item()) < 1.0:
+                failed = True
+                if "error" not in result[key]:
+                    result[key] = {"error": "another rank failed in this sub-record; timings discarded", **result[key]}
+        stage["name"] = "done"
         timer.cancel()
         if printed.is_set():              # the watchdog fired between the last record and cancel()
-            return
+            os._exit(3)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0 would hold the others up)
             result["cpu_baseline"] = cpu_baseline(args, args.workload)

@@ -56,6 +56,10 @@ typedef enum qp_status {
 /* Library version (major*10000 + minor*100 + patch) and last error text of this thread. */
 int qp_version(void);
 const char* qp_last_error(void);
+/* Identity of the build as one JSON object: {"version": .., "arch": "gfx950", "qp_abl": N, "source_hash": "16 hex digits"}.
+ * qp_abl != 0 marks a timing-only ablation build (tools/ablate.sh) whose results are wrong by construction: bench.py
+ * prints this object with every number and refuses to measure such a build. */
+const char* qp_build_info(void);
 
 /* Geometry + per-field diffusivity description passed to the general diffusion kernels. */
 typedef struct qp_grid_desc {
@@ -310,6 +314,18 @@ int qp_adi_rect_phase(qp_adi_rect_plan* plan, int32_t phase, double* u, void* st
 int qp_adi_rect_iface_halo(qp_adi_rect_plan* plan, int32_t dir, int32_t side, int32_t op, double* buf, void* stream);
 /* rows[nfield][nx]: the field row just above (side 0) / below (side 1) the block, consumed by QP_ADI_ENTRY. */
 int qp_adi_rect_set_field_halo(qp_adi_rect_plan* plan, int32_t side, const double* rows, void* stream);
+
+/*
+ * Halo refresh of the overlapped-halo decomposition (one rank per GPU holds its block + halos as u[nfield][ey][ex]):
+ * copies `nrect` rectangular windows between u and ONE packed buffer in a single launch, so that a refresh is
+ * pack -> one batch of RCCL send/recv on persistent buffers -> unpack, with no host synchronisation in between.
+ *   rects  HOST array [nrect][4] = (row0, col0, rows, cols) of each window inside the ey x ex block, nrect <= 8
+ *   buf    windows back to back in `rects` order, each stored [nfield][rows][cols]
+ *   op     0: pack (u -> buf), 1: unpack (buf -> u)
+ * The reference has no distributed path; this serves north_star's "RCCL halo exchange over xGMI".
+ */
+int qp_halo_pack(double* u, int32_t nfield, int32_t ey, int32_t ex, const int32_t* rects, int32_t nrect, int32_t op,
+                 double* buf, void* stream);
 
 /*
  * Tiled CN-ADI path for MASKED grids: any mask, any per-face boundary condition, one diffusivity per field

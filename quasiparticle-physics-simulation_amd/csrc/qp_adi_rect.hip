@@ -784,6 +784,8 @@ static int fine_phase(qp_adi_rect_plan* plan, int phase, double* u, hipStream_t 
   return check_launch("qp_adi_rect_phase (fine tiles)");
 }
 
+int rect_ablation_mask() { return QP_ABL; }
+
 }  // namespace qp
 
 extern "C" {
@@ -1149,7 +1151,9 @@ int qp_adi_rect_combine(qp_adi_rect_plan* plan, const double* u, const double* r
   long blocks = (v.d.nx & 3) == 0 ? (long)v.d.nfield * ((v.d.ny + 7) / 8) * ((v.d.nx + 1023) / 1024)
                                   : (long)v.d.nfield * v.d.ny;
   if (blocks > 1024) blocks = 1024;         // = the partial slots of the reduction workspace
-  QP_REQUIRE(((uintptr_t)u | (uintptr_t)out | (uintptr_t)rin) % 16 == 0, "u, rin, out must be 16-byte aligned");
+  // only the 4-cells-per-thread branch makes 16-byte accesses (per-field views with odd ncell take the row branch)
+  QP_REQUIRE((v.d.nx & 3) != 0 || ((uintptr_t)u | (uintptr_t)out | (uintptr_t)rin) % 16 == 0,
+             "u, rin, out must be 16-byte aligned when nx is a multiple of 4");
   RectSides g{plan->bc_diag[0], plan->bc_diag[1], plan->bc_diag[2], plan->bc_diag[3],
               plan->bc_src[0], plan->bc_src[1], plan->bc_src[2], plan->bc_src[3]};
   if (v.d.nx == 1) { g.dr = 0.0; g.sr = 0.0; }   // one column: rect_side_terms folds both x-faces into the "left" slot
@@ -1168,6 +1172,8 @@ int qp_adi_rect_combine(qp_adi_rect_plan* plan, const double* u, const double* r
 int qp_adi_rect_iface_halo(qp_adi_rect_plan* plan, int32_t dir, int32_t side, int32_t op, double* buf, void* stream) {
   QP_REQUIRE(plan && buf, "plan and buf must be non-NULL");
   QP_REQUIRE((dir == 0 || dir == 1) && (side == 0 || side == 1) && (op == 0 || op == 1), "dir, side, op must be 0 or 1");
+  // only block plans of a decomposed grid own interface rows (Peaceman-Rachford plans on fine tiles allocate none)
+  QP_REQUIRE(plan->decomposed && plan->pr_scale == 0.0, "only plans of qp_adi_rect_plan_create_block on a decomposed grid exchange interface rows");
   const qp::RectView& v = plan->view;
   const size_t nlines = dir == 0 ? v.d.ny : v.d.nx;
   const int P = dir == 0 ? v.d.px : v.d.py;
@@ -1190,6 +1196,7 @@ int qp_adi_rect_iface_halo(qp_adi_rect_plan* plan, int32_t dir, int32_t side, in
 // Field rows just above (side 0) / below (side 1) the local block, [nfield][nx], for the entry pass of a decomposed plan.
 int qp_adi_rect_set_field_halo(qp_adi_rect_plan* plan, int32_t side, const double* rows, void* stream) {
   QP_REQUIRE(plan && rows && (side == 0 || side == 1), "bad arguments");
+  QP_REQUIRE(plan->decomposed && plan->pr_scale == 0.0, "only plans of qp_adi_rect_plan_create_block on a decomposed grid take field halo rows");
   const qp::RectView& v = plan->view;
   hipError_t e = hipMemcpyAsync(plan->d_uhalo[side], rows, (size_t)v.d.nfield * v.d.nx * sizeof(double),
                                 hipMemcpyDeviceToDevice, (hipStream_t)stream);

@@ -606,6 +606,8 @@ __global__ void __launch_bounds__(256) tile_var_weights_kernel(TileView v, const
   rdy[(long)b * pcell + qc] = r * d;
 }
 
+int tile_ablation_mask() { return QP_ABL; }
+
 }  // namespace qp
 
 struct qp_adi_tile_plan {

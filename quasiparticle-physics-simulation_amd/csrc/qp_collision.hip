@@ -225,7 +225,9 @@ extern "C" int qp_collision_step(const qp_collision_tables* t, const uint8_t* fl
 }
 
 extern "C" int64_t qp_collision_guard_workspace_bytes(int64_t ncell) {
-  const int64_t waves = (ncell + 63) / 64 + qp::kGuardMergeBlocks;
+  // the register kernels launch ceil(ncell / 128) blocks of two waves and EVERY wave writes a partial (also the second wave
+  // of a last block that holds <= 64 cells), so the count follows the launch geometry, not ceil(ncell / 64)
+  const int64_t waves = 2 * ((ncell + 127) / 128) + qp::kGuardMergeBlocks;
   const int64_t fused = waves * (int64_t)sizeof(qp::PauliPartial);
   const int64_t plain = qp_pauli_workspace_bytes();
   return fused > plain ? fused : plain;

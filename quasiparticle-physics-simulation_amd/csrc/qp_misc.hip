@@ -199,6 +199,49 @@ __global__ void __launch_bounds__(256) axpy_kernel(long n, double alpha, const d
     y[t] += alpha * x[t];
 }
 
+// Windows of an extended block <-> one packed buffer (halo refresh of the overlapped-halo decomposition).  blockIdx.y is
+// the window; a thread moves two neighbouring doubles of one window row when the window width and both addresses allow
+// 16-byte accesses (the 64-wide strips of the decomposition always do), single doubles otherwise.
+struct HaloRects {
+  int n;
+  int row0[8], col0[8], rows[8], cols[8];
+  long offset[8];      // start of the window in the packed buffer, in doubles
+};
+
+template <bool PACK>
+__global__ void __launch_bounds__(256) halo_pack_kernel(double* __restrict__ u, int nfield, int ey, int ex, HaloRects r,
+                                                        double* __restrict__ buf) {
+  const int w = blockIdx.y;
+  const int rows = r.rows[w], cols = r.cols[w];
+  const long plane = (long)ey * ex;
+  double* b = buf + r.offset[w];
+  double* base = u + (long)r.row0[w] * ex + r.col0[w];
+  const bool pair = (cols & 1) == 0 && (ex & 1) == 0 && (r.col0[w] & 1) == 0 && (r.offset[w] & 1) == 0 &&
+                    (((unsigned long long)u | (unsigned long long)buf) & 15) == 0;
+  if (pair) {
+    const int hc = cols >> 1;
+    const long total = (long)nfield * rows * hc;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+      const int c = (int)(t % hc);
+      const long fr = t / hc;
+      const int j = (int)(fr % rows), f = (int)(fr / rows);
+      double2* pu = reinterpret_cast<double2*>(base + (long)f * plane + (long)j * ex) + c;
+      double2* pb = reinterpret_cast<double2*>(b + ((long)f * rows + j) * cols) + c;
+      if (PACK) *pb = *pu; else *pu = *pb;
+    }
+  } else {
+    const long total = (long)nfield * rows * cols;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+      const int c = (int)(t % cols);
+      const long fr = t / cols;
+      const int j = (int)(fr % rows), f = (int)(fr / rows);
+      double* pu = base + (long)f * plane + (long)j * ex + c;
+      double* pb = b + ((long)f * rows + j) * cols + c;
+      if (PACK) *pb = *pu; else *pu = *pb;
+    }
+  }
+}
+
 static inline unsigned grid_for(long n) {
   long b = (n + 255) / 256;
   return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
@@ -274,6 +317,36 @@ int qp_absmax(const double* a, int64_t n, void* workspace, double* out_val, void
   hipLaunchKernelGGL(qp::absmax_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace,
                      (int)blocks, out_val);
   return qp::check_launch("qp_absmax");
+}
+
+int qp_halo_pack(double* u, int32_t nfield, int32_t ey, int32_t ex, const int32_t* rects, int32_t nrect, int32_t op,
+                 double* buf, void* stream) {
+  QP_REQUIRE(u && buf && rects, "u, buf, rects must be non-NULL");
+  QP_REQUIRE(nfield > 0 && ey > 0 && ex > 0, "nfield, ey, ex must be positive");
+  QP_REQUIRE(nrect >= 1 && nrect <= 8, "1 to 8 windows per call");
+  QP_REQUIRE(op == 0 || op == 1, "op must be 0 (pack) or 1 (unpack)");
+  qp::HaloRects r;
+  r.n = nrect;
+  long off = 0, largest = 0;
+  for (int w = 0; w < nrect; ++w) {
+    r.row0[w] = rects[4 * w]; r.col0[w] = rects[4 * w + 1]; r.rows[w] = rects[4 * w + 2]; r.cols[w] = rects[4 * w + 3];
+    QP_REQUIRE(r.rows[w] > 0 && r.cols[w] > 0 && r.row0[w] >= 0 && r.col0[w] >= 0 && r.row0[w] + r.rows[w] <= ey &&
+                   r.col0[w] + r.cols[w] <= ex, "window outside the block");
+    r.offset[w] = off;
+    const long cells = (long)nfield * r.rows[w] * r.cols[w];
+    off += cells;
+    if (cells > largest) largest = cells;
+  }
+  long bx = (largest / 2 + 255) / 256;
+  if (bx > 2048) bx = 2048;
+  if (bx < 1) bx = 1;
+  if (op == 0)
+    hipLaunchKernelGGL(qp::halo_pack_kernel<true>, dim3((unsigned)bx, (unsigned)nrect), dim3(256), 0, (hipStream_t)stream, u,
+                       (int)nfield, (int)ey, (int)ex, r, buf);
+  else
+    hipLaunchKernelGGL(qp::halo_pack_kernel<false>, dim3((unsigned)bx, (unsigned)nrect), dim3(256), 0, (hipStream_t)stream, u,
+                       (int)nfield, (int)ey, (int)ex, r, buf);
+  return qp::check_launch("qp_halo_pack");
 }
 
 int qp_axpy(int64_t n, double alpha, const double* x, double* y, void* stream) {

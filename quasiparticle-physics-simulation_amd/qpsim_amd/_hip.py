@@ -53,6 +53,9 @@ class TilePlan(C.Structure):
 SIGNATURES = {
     "qp_version": (C.c_int, []),
     "qp_last_error": (C.c_char_p, []),
+    "qp_build_info": (C.c_char_p, []),
+    "qp_halo_pack": (C.c_int, [c_dp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, c_dp,
+                               c_dp]),
     "qp_stencil_combine": (C.c_int, [C.POINTER(GridDesc), C.c_double, c_dp, c_dp, c_dp, C.c_double, C.c_double,
                                      C.c_double, C.c_double, C.c_double, c_dp]),
     "qp_stencil_combine_norm": (C.c_int, [C.POINTER(GridDesc), C.c_double, c_dp, c_dp, c_dp, C.c_double, C.c_double,
@@ -136,6 +139,14 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def build_info() -> dict:
+    """``qp_build_info()`` parsed, plus the path of the library that answered."""
+    import json
+    info = json.loads(load().qp_build_info().decode())
+    info["library"] = str(library_path())
+    return info
 
 
 class QPHipError(RuntimeError):

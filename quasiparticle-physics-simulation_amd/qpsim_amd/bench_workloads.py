@@ -72,6 +72,11 @@ class ADIWorkload:
 
     run_steps = run
 
+    @staticmethod
+    def sweep_launches(k: int) -> int:
+        """Tile-sweep launches of one ``run(k)``: the entry pass + an x- and a y-sweep per step."""
+        return 2 * int(k) + 1
+
     def _pmc_traffic(self):
         """HBM bytes per sweep from the committed PMC summaries (profiles/, separate rocprofv3 --pmc passes of this same
         command); only the configurations that were measured get a number."""
@@ -400,11 +405,15 @@ class OverlapDecomposedWorkload:
     (``distributed.halo_steps_bound``); ``coupled=True`` adds the collision half-steps (full physics, NE = 12) on the
     decomposed grid.  Strong scaling: the global grid is fixed."""
 
-    def __init__(self, N: int, device, coupled: bool = False, steps_per_exchange=None, topo=None):
+    def __init__(self, N: int, device, coupled: bool = False, steps_per_exchange=None, topo=None, halo: int | None = None):
         """``topo``: a ``BlockTopology`` makes this the block of one VIRTUAL rank (several of them in one process, driven by
-        ``distributed.lockstep_overlap_steps``: tests on one GPU); default: the rank of this process in torch.distributed."""
+        ``distributed.lockstep_overlap_steps``: tests on one GPU); default: the rank of this process in torch.distributed.
+        ``halo``: halo width in cells (default ``QPSIM_DD_HALO`` or 64; 128 quadruples the steps between refreshes)."""
+        import os
         import torch.distributed as dist
-        from .distributed import BlockTopology, HipOverlapBlock, OverlapBlock, TorchDistTransport, choose_process_grid
+        from .distributed import (HALO, BlockTopology, HipHaloPacking, HipOverlapBlock, OverlapBlock, TorchDistTransport,
+                                  choose_process_grid)
+        halo = int(os.environ.get("QPSIM_DD_HALO", HALO)) if halo is None else int(halo)
         if topo is None:
             self.world = dist.get_world_size() if dist.is_initialized() else 1
             rank = dist.get_rank() if dist.is_initialized() else 0
@@ -417,7 +426,7 @@ class OverlapDecomposedWorkload:
         self.coupled = coupled
         j0, i0, ny, nx = self.topo.block
         if not coupled:
-            self.block = HipOverlapBlock(self.topo, 1.0, 0.1, [6.0], [0.0] * 4, [0.0] * 4, device=device,
+            self.block = HipOverlapBlock(self.topo, 1.0, 0.1, [6.0], [0.0] * 4, [0.0] * 4, device=device, halo=halo,
                                          steps_per_exchange=steps_per_exchange)
             torch = self.block.torch
             ej, ei = self.block.ext_origin()
@@ -426,11 +435,12 @@ class OverlapDecomposedWorkload:
             self.device = self.block.device
         else:
             import torch
+            torch_mod = torch
             ne = 12
             E, _ = T.build_energy_grid(180.0, 1.0, 3.0, ne)
             dmax = float(np.max(T.diffusion_coefficients(E, 180.0, 6.0)))
             # collision half-steps between the sweeps: same locality argument, half the cadence for margin
-            probe = OverlapBlock(self.topo, ne, 0.5 * 0.1 * dmax, steps_per_exchange=steps_per_exchange)
+            probe = OverlapBlock(self.topo, ne, 0.5 * 0.1 * dmax, halo=halo, steps_per_exchange=steps_per_exchange)
             spe = max(1, probe.steps_per_exchange // 2)
             dev = torch.device(device)
             ej, ei = probe.ext_origin()
@@ -438,7 +448,9 @@ class OverlapDecomposedWorkload:
                 torch, ej, ei, probe.ey, probe.ex, dev).reshape(-1))
             outer = self
 
-            class _Block(OverlapBlock):
+            class _Block(HipHaloPacking, OverlapBlock):
+                torch = torch_mod
+
                 @property
                 def u(self):       # the collision calls swap state / alt: always the current quasiparticle planes
                     return outer.inner.state.view(ne, self.ey, self.ex)
@@ -450,7 +462,7 @@ class OverlapDecomposedWorkload:
                 def advance(self, nsteps):
                     outer.inner.run(nsteps)
 
-            self.block = _Block(self.topo, ne, 0.5 * 0.1 * dmax, steps_per_exchange=spe)
+            self.block = _Block(self.topo, ne, 0.5 * 0.1 * dmax, halo=halo, steps_per_exchange=spe)
             self.nfield = ne
             self.device = dev
         self.N, self.grid = N, [N, N]
@@ -460,7 +472,8 @@ class OverlapDecomposedWorkload:
         self.halo_overhead = b.ey * b.ex / float(ny * nx) - 1.0
         self.path = (f"overlapped-halo decomposition {py}x{px}: block {ny}x{nx} + halo {b.halo} = {b.ey}x{b.ex} per rank "
                      f"(+{100 * self.halo_overhead:.1f} % cells), halo refresh every {b.steps_per_exchange} steps "
-                     f"(x strips then y strips, point-to-point over RCCL), rect-tiled partition ADI"
+                     f"(one round: side strips + corner blocks packed into one send buffer, point-to-point over RCCL), "
+                     f"rect-tiled partition ADI"
                      + (", fine tiles (32-cell chunks)" if getattr(getattr(b, "plan", None), "fine", False) else "")
                      + (" + register collision kernel" if coupled else ""))
         self.description = (f"{N}x{N} fp64 " + ("coupled step C(dt/2) D(dt) C(dt/2), NE=12, " if coupled else "CN-ADI step, ")

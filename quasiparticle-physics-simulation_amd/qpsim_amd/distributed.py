@@ -69,6 +69,14 @@ class BlockTopology:
         i0, nx = split_extent(self.gnx, self.px)[rx]
         return j0, i0, ny, nx
 
+    def neighbour_at(self, drow: int, dcol: int) -> int | None:
+        """Rank of the block ``drow`` block-rows down and ``dcol`` block-columns right of this one (diagonals included)."""
+        ry, rx = self.coords
+        ry, rx = ry + drow, rx + dcol
+        if (drow or dcol) and 0 <= ry < self.py and 0 <= rx < self.px:
+            return ry * self.px + rx
+        return None
+
     def neighbour(self, direction: int, side: int) -> int | None:
         """Rank next to this block: direction 0 = along x (side 0 left, 1 right), 1 = along y (0 up, 1 down)."""
         ry, rx = self.coords
@@ -295,14 +303,18 @@ class HipBlockBackend:
 # data and cuts the lines at the OUTER edge of that halo therefore computes its OWN cells with an error ~ rho^H per step
 # (1e-45 for H = 64, r D = 0.3) - the same "below fp64 significance" argument by which the tiled kernels drop the far
 # couplings between 64-cell chunks (qp_tile_common.h, kFarCouplingDrop = 1e-22).  The cut error creeps inwards by a few
-# cells per step, so the halo stays good for S steps (``halo_steps_bound``: 19 for r D = 0.3, H = 64; conservative bound
-# 1e-20 relative) before it has to be refreshed from the neighbours.  Between refreshes a rank runs the ORDINARY
-# single-GPU kernels on its extended block - S steps in one library call, 32 B per cell-update, no interface traffic -
-# and a refresh is one bulk exchange of H-wide strips (x first, then y across the already refreshed x-halos, which
-# fills the corners without diagonal messages).  Compared with the exact interface exchange above (``block_adi_steps``:
-# two latency-bound messages per step on the critical path) this trades ~2 H / n extra cells for 2 S times fewer, larger
-# messages; it is the mode the strong-scaling benchmark uses, the exact scheme remains for stiff steps (S < 1).
+# cells per step, so the halo stays good for S steps (``halo_steps_bound``: 19 for r D = 0.3, H = 64, 63 for H = 128;
+# conservative bound 1e-20 relative) before it has to be refreshed from the neighbours.  Between refreshes a rank runs the
+# ORDINARY single-GPU kernels on its extended block - S steps in one library call, 32 B per cell-update, no interface
+# traffic.  A refresh is ONE round of point-to-point messages: every rank packs the H-wide strips for its side neighbours
+# and the H x H corner blocks for its diagonal neighbours into one persistent send buffer (one kernel), posts all sends
+# and receives of the round as one batch, and unpacks the persistent receive buffer into its halos (one kernel).  On the
+# RCCL path nothing in a refresh blocks the host: the batch is ordered after the pack kernel and before the unpack kernel
+# by stream dependencies.  Compared with the exact interface exchange above (``block_adi_steps``: two latency-bound
+# messages per step on the critical path) this trades ~2 H / n extra cells for 2 S times fewer, larger messages; it is
+# the mode the strong-scaling benchmark uses, the exact scheme remains for stiff steps (S < 1).
 HALO = 64
+NEIGHBOUR_OFFSETS = ((-1, -1), (-1, 0), (-1, 1), (0, -1), (0, 1), (1, -1), (1, 0), (1, 1))     # (rows, columns) of the 8 peers
 
 
 def halo_steps_bound(a: float, halo: int = HALO, limit: float = 1e-20, cap: int = 64) -> int:
@@ -333,12 +345,51 @@ def halo_steps_bound(a: float, halo: int = HALO, limit: float = 1e-20, cap: int 
     return steps
 
 
+def halo_cost_model(topo: "BlockTopology", a: float, nfield: int = 1, candidates=(64, 128), step_us_per_mcell: float = 5.6,
+                    refresh_latency_us: float = 120.0, link_gbs: float = 50.0) -> dict:
+    """Per-step time of the slowest rank as a function of the halo width H: the kernels run on the block + its halos every
+    step, a refresh costs a fixed latency + the bytes of the largest message over one xGMI link (the messages of a round
+    travel on different links at the same time) and is due every S(H) = ``halo_steps_bound(a, H)`` steps.
+    ``step_us_per_mcell``: measured cost of one ADI step per million cells (4160 x 2176 block: 51 us);
+    ``refresh_latency_us``: fixed cost of a refresh round (pack + one batch of point-to-point messages + unpack);
+    ``link_gbs``: what one neighbour link delivers.  The bench replaces the defaults with what it measures on the
+    machine.  Returns {"choice": H or None, "table": {H: {...}}}."""
+    table = {}
+    for H in candidates:
+        S = halo_steps_bound(a, H, cap=256)
+        if S < 1:
+            continue
+        worst = None
+        for rank in range(topo.py * topo.px):
+            t = BlockTopology(topo.gny, topo.gnx, topo.py, topo.px, rank)
+            _, _, ny, nx = t.block
+            cut_y = sum(t.neighbour(1, side) is not None for side in (0, 1))
+            cut_x = sum(t.neighbour(0, side) is not None for side in (0, 1))
+            if (cut_y and ny < H) or (cut_x and nx < H):
+                worst = None
+                break
+            cells = (ny + cut_y * H) * (nx + cut_x * H)
+            largest = max([H * ny] * bool(cut_x) + [H * nx] * bool(cut_y) + [0])
+            if worst is None or cells > worst[0]:
+                worst = (cells, largest, ny * nx)
+        if worst is None:
+            continue
+        cells, largest, own = worst
+        refresh = refresh_latency_us + 8.0 * nfield * largest / (link_gbs * 1e3)
+        step = step_us_per_mcell * nfield * cells / 1e6
+        table[int(H)] = {"steps_per_refresh": int(S), "cells": int(cells), "step_us": step, "refresh_us": refresh,
+                         "us_per_step": step + refresh / S, "halo_cells_overhead": cells / float(own) - 1.0}
+    if not table:
+        return {"choice": None, "table": table}
+    return {"choice": min(table, key=lambda h: table[h]["us_per_step"]), "table": table}
+
+
 class OverlapBlock:
     """One rank's block of a decomposed full-rectangle grid, extended by ``halo`` cells towards every neighbour.
 
     ``u`` is a torch tensor [nfield, ey, ex] (device of the backend).  Subclasses implement ``advance(n)`` - n ADI steps
     on the extended block with the physical boundary condition on physical sides and a reflective wall at the outer edge
-    of a halo.  Everything about strips, messages and the exchange cadence lives here, so the CPU test backend and the HIP
+    of a halo.  Everything about windows, messages and the exchange cadence lives here, so the CPU test backend and the HIP
     backend run the same orchestration."""
 
     def __init__(self, topo: BlockTopology, nfield: int, a_max: float, halo: int = HALO, steps_per_exchange=None):
@@ -351,13 +402,15 @@ class OverlapBlock:
             raise ValueError(f"blocks of {ny} x {nx} cells are smaller than the halo ({halo})")
         self.ny, self.nx = ny, nx
         self.ey, self.ex = ny + self.hu + self.hd, nx + self.hl + self.hr
-        bound = halo_steps_bound(a_max, halo)
+        bound = halo_steps_bound(a_max, halo, cap=256)
         self.steps_per_exchange = bound if steps_per_exchange is None else min(int(steps_per_exchange), bound)
         if self.steps_per_exchange < 1 and topo.py * topo.px > 1:
             raise ValueError(f"r D = {a_max:.3g} is too stiff for the overlapped-halo scheme with a halo of {halo} cells; "
                              "use the exact interface exchange (block_adi_steps)")
         self.since_exchange = 0
         self.u = None        # set by the subclass
+        self._windows = None
+        self._send_buf = self._recv_buf = None
 
     # -- the block inside the extended array ----------------------------------------------------------------------
     @property
@@ -375,53 +428,90 @@ class OverlapBlock:
         return ([0.0 if c else float(v) for c, v in zip(cut, bc_diag)],
                 [0.0 if c else float(v) for c, v in zip(cut, bc_src)])
 
-    # -- strips ----------------------------------------------------------------------------------------------------
-    def _send_strip(self, direction: int, side: int):
-        H = self.halo
-        if direction == 0:       # my first / last H own columns, own rows only
-            c0 = self.hl if side == 0 else self.hl + self.nx - H
-            return self.u[:, self.hu:self.hu + self.ny, c0:c0 + H]
-        r0 = self.hu if side == 0 else self.hu + self.ny - H
-        return self.u[:, r0:r0 + H, :]            # full extended width: carries the x-halos into the corners
+    # -- windows of one refresh round -----------------------------------------------------------------------------
+    def windows(self):
+        """[(peer, send window, receive window)] of one refresh, one entry per existing neighbour (sides and diagonals);
+        a window is (row0, col0, rows, cols) inside the extended block.  What I send towards offset (dr, dc) is the part of
+        my OWN cells within ``halo`` of that side / corner; what I receive from there lands in the halo on that side."""
+        if self._windows is None:
+            H = self.halo
 
-    def _recv_strip(self, direction: int, side: int):
-        if direction == 0:
-            c0 = 0 if side == 0 else self.hl + self.nx
-            return self.u[:, self.hu:self.hu + self.ny, c0:c0 + self.halo]
-        r0 = 0 if side == 0 else self.hu + self.ny
-        return self.u[:, r0:r0 + self.halo, :]
+            def span(d, lead, n):            # (send start, receive start, length) along one axis for offset d
+                if d < 0:
+                    return lead, lead - H, H
+                if d > 0:
+                    return lead + n - H, lead + n, H
+                return lead, lead, n
 
-    def exchange_messages(self, direction: int):
-        """(sends, recvs, unpack) of the halo refresh along ``direction`` (0: left/right strips, 1: up/down strips)."""
-        sends, recvs, after = {}, {}, []
-        for side in (0, 1):
-            peer = self.topo.neighbour(direction, side)
-            if peer is None:
-                continue
-            sends[peer] = self._send_strip(direction, side).contiguous()
-            dst = self._recv_strip(direction, side)
-            buf = dst.new_empty(dst.shape)
-            recvs[peer] = buf
-            after.append(lambda d=dst, b=buf: d.copy_(b))
-        return sends, recvs, after
+            out = []
+            for dr, dc in NEIGHBOUR_OFFSETS:
+                peer = self.topo.neighbour_at(dr, dc)
+                if peer is None:
+                    continue
+                sr, rr, nr = span(dr, self.hu, self.ny)
+                sc, rc, nc = span(dc, self.hl, self.nx)
+                out.append((peer, (sr, sc, nr, nc), (rr, rc, nr, nc)))
+            self._windows = out
+        return self._windows
+
+    def _buffers(self):
+        """Persistent packed send / receive buffers of the refresh and their per-peer views (allocated once)."""
+        if self._send_buf is None:
+            sizes = [self.nfield * w[1][2] * w[1][3] for w in self.windows()]
+            total = max(int(sum(sizes)), 1)
+            self._send_buf = self.u.new_empty(total)
+            self._recv_buf = self.u.new_empty(total)
+            self._views, off = [], 0
+            for (peer, sw, rw), n in zip(self.windows(), sizes):
+                shape = (self.nfield, sw[2], sw[3])
+                self._views.append((peer, self._send_buf[off:off + n].view(shape), self._recv_buf[off:off + n].view(shape)))
+                off += n
+        return self._views
+
+    def pack(self) -> None:
+        """Own cells near every neighbour -> the packed send buffer (device-agnostic fallback: one slice copy per window)."""
+        for (peer, (r, c, nr, nc), _), (_, sview, _) in zip(self.windows(), self._buffers()):
+            sview.copy_(self.u[:, r:r + nr, c:c + nc])
+
+    def unpack(self) -> None:
+        for (peer, _, (r, c, nr, nc)), (_, _, rview) in zip(self.windows(), self._buffers()):
+            self.u[:, r:r + nr, c:c + nc].copy_(rview)
+
+    def refresh_messages(self):
+        """(sends, recvs) of one refresh round: per-peer views of the persistent packed buffers.  Call ``pack()`` before
+        the exchange and ``unpack()`` after it."""
+        views = self._buffers()
+        return {peer: s for peer, s, _ in views}, {peer: r for peer, _, r in views}
+
+    @property
+    def refresh_bytes(self) -> int:
+        """Bytes this rank receives per refresh."""
+        return 8 * sum(self.nfield * w[2][2] * w[2][3] for w in self.windows())
 
     def advance(self, nsteps: int) -> None:
         raise NotImplementedError
 
 
 def overlap_stages(nsteps: int, steps_per_exchange: int, since_exchange: int):
-    """("steps", n) and ("exchange", direction) stages of ``nsteps`` steps; returns through StopIteration nothing - the caller
-    tracks ``since_exchange`` with the same arithmetic (``overlap_advance_counter``)."""
+    """("steps", n) and ("refresh", None) stages of ``nsteps`` steps (a refresh is ONE round of messages); the caller tracks
+    ``since_exchange`` with the same arithmetic."""
     left, since = int(nsteps), int(since_exchange)
     while left > 0:
         if since >= steps_per_exchange:
-            yield ("exchange", 0)
-            yield ("exchange", 1)
+            yield ("refresh", None)
             since = 0
         n = min(left, steps_per_exchange - since)
         yield ("steps", n)
         left -= n
         since += n
+
+
+def refresh_halos(block: OverlapBlock, transport) -> None:
+    """One refresh of ``block``'s halos over ``transport`` (real ranks: every process calls this collectively)."""
+    block.pack()
+    sends, recvs = block.refresh_messages()
+    transport.exchange(sends, recvs)
+    block.unpack()
 
 
 def overlap_adi_steps(block: OverlapBlock, transport, nsteps: int, exchange: bool = True) -> None:
@@ -433,18 +523,10 @@ def overlap_adi_steps(block: OverlapBlock, transport, nsteps: int, exchange: boo
         if kind == "steps":
             block.advance(arg)
             block.since_exchange += arg
-        elif arg == 0:
+        else:
             block.since_exchange = 0
             if exchange and not single:
-                sends, recvs, after = block.exchange_messages(0)
-                transport.exchange(sends, recvs)
-                for fn in after:
-                    fn()
-        elif exchange and not single:
-            sends, recvs, after = block.exchange_messages(1)
-            transport.exchange(sends, recvs)
-            for fn in after:
-                fn()
+                refresh_halos(block, transport)
 
 
 def lockstep_overlap_steps(blocks: list, nsteps: int) -> None:
@@ -457,20 +539,75 @@ def lockstep_overlap_steps(blocks: list, nsteps: int) -> None:
                 b.advance(arg)
                 b.since_exchange += arg
             continue
-        pending = []
         for b in blocks:
-            if arg == 0:
-                b.since_exchange = 0
-            sends, recvs, after = b.exchange_messages(arg)
-            mail.post(b.topo.rank, sends)
-            pending.append((b.topo.rank, recvs, after))
-        for rank, recvs, after in pending:
-            mail.collect(rank, recvs)
-            for fn in after:
-                fn()
+            b.since_exchange = 0
+            b.pack()
+            mail.post(b.topo.rank, b.refresh_messages()[0])
+        for b in blocks:
+            mail.collect(b.topo.rank, b.refresh_messages()[1])
+            b.unpack()
 
 
-class HipOverlapBlock(OverlapBlock):
+def measure_refresh(block: OverlapBlock, transport, reps: int = 5, sync=None) -> dict:
+    """Host wall-clock of the stages of a refresh (pack, exchange, unpack), each bracketed by ``sync()`` (device
+    synchronisation; default: none, for CPU blocks) - microseconds, averaged over ``reps`` refreshes after one untimed.
+    Timing only: the halos are simply refreshed again, results are unaffected."""
+    import time
+    sync = sync or (lambda: None)
+    acc = {"pack_us": 0.0, "exchange_us": 0.0, "unpack_us": 0.0}
+    for rep in range(reps + 1):
+        sends, recvs = block.refresh_messages()
+        sync()
+        t0 = time.perf_counter()
+        block.pack()
+        sync()
+        t1 = time.perf_counter()
+        transport.exchange(sends, recvs)
+        sync()
+        t2 = time.perf_counter()
+        block.unpack()
+        sync()
+        t3 = time.perf_counter()
+        if rep:
+            acc["pack_us"] += 1e6 * (t1 - t0)
+            acc["exchange_us"] += 1e6 * (t2 - t1)
+            acc["unpack_us"] += 1e6 * (t3 - t2)
+    out = {k: v / reps for k, v in acc.items()}
+    out["refresh_us"] = sum(out.values())
+    out["bytes_received"] = block.refresh_bytes
+    return out
+
+
+class HipHaloPacking:
+    """``pack`` / ``unpack`` of an ``OverlapBlock`` whose ``u`` is a contiguous device tensor [nfield, ey, ex]: all windows of
+    a refresh in ONE kernel each way (``qp_halo_pack``)."""
+
+    def _halo_pack_call(self, op: int) -> None:
+        import ctypes as C
+        from . import _hip
+        views = self._buffers()
+        if not views:
+            return
+        u = self.u
+        if not u.is_contiguous():
+            raise ValueError("the extended block must be one contiguous [nfield, ey, ex] tensor")
+        which = 1 if op == 0 else 2
+        rects = [v for w in self.windows() for v in w[which]]
+        arr = (C.c_int32 * len(rects))(*rects)
+        buf = self._send_buf if op == 0 else self._recv_buf
+        torch = self.torch
+        stream = int(torch.cuda.current_stream(u.device).cuda_stream)
+        _hip.check(_hip.load().qp_halo_pack(int(u.data_ptr()), self.nfield, self.ey, self.ex, arr, len(self.windows()), op,
+                                            int(buf.data_ptr()), stream), "qp_halo_pack")
+
+    def pack(self) -> None:
+        self._halo_pack_call(0)
+
+    def unpack(self) -> None:
+        self._halo_pack_call(1)
+
+
+class HipOverlapBlock(HipHaloPacking, OverlapBlock):
     """Overlapped-halo block on one GPU: an ordinary (undecomposed) ``qp_adi_rect_plan`` on the extended block."""
 
     def __init__(self, topo: BlockTopology, dx: float, dt: float, dcoef, bc_diag, bc_src, halo: int = HALO, device=None,
@@ -479,7 +616,7 @@ class HipOverlapBlock(OverlapBlock):
         from .engine import RectPlan, require_gpu
         torch = require_gpu()
         r = 0.5 * dt / (dx * dx)
-        super().__init__(topo, len(dcoef), r * float(max(dcoef)), halo, steps_per_exchange)
+        OverlapBlock.__init__(self, topo, len(dcoef), r * float(max(dcoef)), halo, steps_per_exchange)
         self.torch, self.lib, self._hip = torch, _hip.load(), _hip
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         bd, bs = self.side_bcs(bc_diag, bc_src)

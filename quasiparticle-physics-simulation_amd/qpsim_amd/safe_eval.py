@@ -109,6 +109,48 @@ def _strip_return(source: str) -> str:
     return text
 
 
+_SHAPE_AWARE_NP = frozenset("arange zeros_like ones_like full_like".split())
+
+
+def expression_is_elementwise(source: str, *, array_variables: Iterable[str]) -> bool:
+    """True when ``source`` treats the variables in ``array_variables`` purely element by element: arithmetic, comparisons
+    and the elementwise ``np.*`` functions only - no subscripts, ``.size`` / ``.shape``, ``len``, conditional expressions,
+    ``and`` / ``or``, builtins or ``math.*`` applied to them.  Such an expression gives the same values whether it is
+    evaluated bin by bin or once on broadcast arrays, which is what ``solver.evaluate_external_generation`` uses to
+    evaluate a custom generation rate in ONE call.  (Syntax errors answer False; validation is not this function's job.)"""
+    arrays = frozenset(array_variables)
+    try:
+        tree = ast.parse(_strip_return(source), mode="eval")
+    except SyntaxError:
+        return False
+
+    def touches_arrays(node: ast.AST) -> bool:
+        return any(isinstance(n, ast.Name) and n.id in arrays for n in ast.walk(node))
+
+    for node in ast.walk(tree):
+        if isinstance(node, (ast.IfExp, ast.BoolOp)) and touches_arrays(node):
+            return False
+        if isinstance(node, ast.UnaryOp) and isinstance(node.op, ast.Not) and touches_arrays(node):
+            return False
+        if isinstance(node, ast.Compare) and len(node.ops) > 1 and touches_arrays(node):
+            return False       # a < x < b is an implicit `and`
+        if isinstance(node, ast.Subscript) and touches_arrays(node):
+            return False
+        if isinstance(node, ast.Attribute) and isinstance(node.value, ast.Name) and node.value.id in arrays:
+            return False
+        if isinstance(node, (ast.Tuple, ast.List, ast.Dict)) and touches_arrays(node):
+            return False
+        if isinstance(node, ast.Call):
+            fn = node.func
+            operands = list(node.args) + [kw.value for kw in node.keywords]
+            if not any(touches_arrays(a) for a in operands):
+                continue
+            if not (isinstance(fn, ast.Attribute) and isinstance(fn.value, ast.Name) and fn.value.id == "np"
+                    and fn.attr in _NP_FUNCS - _SHAPE_AWARE_NP):
+                return False
+    return True
+
+
 def compile_safe_expression(source: str, *, variable_names: Iterable[str]) -> Callable[..., Any]:
     """Validate ``source`` and return ``evaluate(**variables)``; all declared variables are required."""
     required = tuple(variable_names)

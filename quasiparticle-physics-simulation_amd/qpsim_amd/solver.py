@@ -94,58 +94,92 @@ def build_fixed_phonon_history(*, mask: np.ndarray, times, bath_temperature: flo
     return frames, eframes, bins, meta
 
 
-def evaluate_external_generation(spec: ExternalGenerationSpec, E_bins: np.ndarray, n_spatial: int, t: float,
-                                 mask: np.ndarray) -> np.ndarray | None:
-    """g_ext(E, x, t) as an [NE, n_spatial] host array, None for mode "none" (solver.py:878-964).
+def _validated_generation(rates: np.ndarray, mode: str, shape: tuple[int, int]) -> np.ndarray:
+    """Shape / finiteness / sign checks every generation mode goes through (messages of solver.py:889-902)."""
+    if rates.shape != shape:
+        raise ValueError(f"External generation mode '{mode}' returned invalid shape {rates.shape}; expected {shape}.")
+    if not np.isfinite(rates).all():
+        raise ValueError(f"External generation mode '{mode}' produced non-finite values.")
+    if (rates < 0).any():
+        raise ValueError(f"External generation mode '{mode}' produced negative values. "
+                         "Generation rates must be non-negative.")
+    return rates
 
-    The run loop only calls this for ``custom`` mode; constant / pulse rates are added on the device.
+
+class _CustomGeneration:
+    """A ``custom`` generation expression g(E, x, y, t, params) compiled once, evaluated on [NE, n_spatial].
+
+    Three evaluation strategies, tried in this order, each falling through to the next on ANY exception:
+      grid      one call with E as a column and x, y as rows - only for expressions that are elementwise in E, x, y
+                (``safe_eval.expression_is_elementwise``), where broadcasting cannot change a value;
+      per bin   one call per energy bin with E a scalar and x, y arrays: the reference's vectorised attempt
+                (solver.py:933-948), incl. its rule that a bin yields a scalar or exactly n_spatial values;
+      per cell  one call per (bin, pixel) with plain floats: the reference's scalar fallback (solver.py:949-961), whose
+                exceptions are the caller's.
+    x, y are the normalised pixel-centre coordinates of the interior cells in argwhere order (solver.py:924-929)."""
+
+    def __init__(self, spec: ExternalGenerationSpec, mask: np.ndarray):
+        from .safe_eval import expression_is_elementwise
+        body = spec.custom_body.strip() or "0.0"
+        self._fn = compile_safe_expression(body, variable_names=("E", "x", "y", "t", "params"))
+        self._gridwise = expression_is_elementwise(body, array_variables=("E", "x", "y"))
+        self._params = dict(spec.custom_params or {})
+        mask = np.asarray(mask, dtype=bool)
+        ny, nx = mask.shape
+        rows, cols = np.nonzero(mask)
+        self._x = (cols + 0.5) / max(1, nx)
+        self._y = (rows + 0.5) / max(1, ny)
+
+    def _on_grid(self, E: np.ndarray, t: float, shape) -> np.ndarray:
+        value = self._fn(E=E[:, None], x=self._x[None, :], y=self._y[None, :], t=t, params=self._params)
+        return np.array(np.broadcast_to(np.asarray(value, dtype=float), shape))
+
+    def _per_bin(self, E: np.ndarray, t: float, shape) -> np.ndarray:
+        n = shape[1]
+        out = np.empty(shape, dtype=float)
+        for row, energy in zip(out, E):
+            value = np.asarray(self._fn(E=energy, x=self._x, y=self._y, t=t, params=self._params), dtype=float)
+            if value.ndim and value.size != n:
+                raise ValueError("Vectorized custom generation must return a scalar or "
+                                 f"exactly {n} values per energy bin; got {value.size}.")
+            row[...] = value.reshape(-1) if value.ndim else float(value)
+        return out
+
+    def _per_cell(self, E: np.ndarray, t: float, shape) -> np.ndarray:
+        cells = list(zip(self._x.tolist(), self._y.tolist()))
+        return np.array([[float(self._fn(E=energy, x=x, y=y, t=t, params=self._params)) for x, y in cells]
+                         for energy in E.tolist()], dtype=float).reshape(shape)
+
+    def __call__(self, E_bins: np.ndarray, t: float, n_spatial: int) -> np.ndarray:
+        E = np.asarray(E_bins, dtype=float)
+        shape = (E.size, int(n_spatial))
+        for attempt in ((self._on_grid,) if self._gridwise else ()) + (self._per_bin,):
+            try:
+                return attempt(E, t, shape)
+            except Exception:      # noqa: BLE001 - any failure of a vectorised attempt means "try the next strategy"
+                continue
+        return self._per_cell(E, t, shape)
+
+
+def evaluate_external_generation(spec: ExternalGenerationSpec, E_bins: np.ndarray, n_spatial: int, t: float,
+                                 mask: np.ndarray, _compiled: "_CustomGeneration | None" = None) -> np.ndarray | None:
+    """g_ext(E, x, t) as an [NE, n_spatial] host array, None for mode "none" (semantics of solver.py:878-964).
+
+    The run loop only calls this for ``custom`` mode (constant / pulse rates are added on the device) and passes the
+    expression it compiled once per run as ``_compiled``.
     """
     mode = spec.mode.strip().lower()
-    if mode == "none":
-        return None
-    NE = len(E_bins)
-
-    def checked(arr: np.ndarray) -> np.ndarray:
-        if arr.shape != (NE, n_spatial):
-            raise ValueError(f"External generation mode '{mode}' returned invalid shape {arr.shape}; "
-                             f"expected {(NE, n_spatial)}.")
-        if not np.all(np.isfinite(arr)):
-            raise ValueError(f"External generation mode '{mode}' produced non-finite values.")
-        if np.any(arr < 0):
-            raise ValueError(f"External generation mode '{mode}' produced negative values. "
-                             "Generation rates must be non-negative.")
-        return arr
-
+    shape = (len(E_bins), int(n_spatial))
     if mode == "constant":
-        return checked(np.full((NE, n_spatial), spec.rate, dtype=float))
-    if mode == "pulse":
-        on = spec.pulse_start <= t < spec.pulse_start + spec.pulse_duration
-        return checked(np.full((NE, n_spatial), spec.pulse_rate if on else 0.0, dtype=float))
-    if mode != "custom":
+        level = spec.rate
+    elif mode == "pulse":
+        level = spec.pulse_rate if spec.pulse_start <= t < spec.pulse_start + spec.pulse_duration else 0.0
+    elif mode == "custom":
+        custom = _compiled if _compiled is not None else _CustomGeneration(spec, mask)
+        return _validated_generation(custom(E_bins, t, n_spatial), mode, shape)
+    else:                      # "none" and anything validate() would have rejected
         return None
-    fn = compile_safe_expression(spec.custom_body.strip() or "0.0", variable_names=("E", "x", "y", "t", "params"))
-    ny, nx = mask.shape
-    rows, cols = np.indices(mask.shape)
-    xf = ((cols + 0.5) / max(1, nx))[mask]
-    yf = ((rows + 0.5) / max(1, ny))[mask]
-    params = dict(spec.custom_params or {})
-    out = np.empty((NE, n_spatial), dtype=float)
-    try:
-        for i in range(NE):
-            arr = np.asarray(fn(E=E_bins[i], x=xf, y=yf, t=t, params=params), dtype=float)
-            if arr.ndim == 0:
-                out[i] = float(arr)
-            else:
-                flat = arr.ravel()
-                if flat.size != n_spatial:
-                    raise ValueError("Vectorized custom generation must return a scalar or "
-                                     f"exactly {n_spatial} values per energy bin; got {flat.size}.")
-                out[i] = flat
-    except Exception:
-        for i in range(NE):
-            for px in range(n_spatial):
-                out[i, px] = float(fn(E=float(E_bins[i]), x=float(xf[px]), y=float(yf[px]), t=t, params=params))
-    return checked(out)
+    return _validated_generation(np.full(shape, level, dtype=float), mode, shape)
 
 
 def _crop_to_bounding_box(mask: np.ndarray, edges: list[EdgeSegment]):
@@ -576,6 +610,7 @@ def run_2d_crank_nicolson(
                        and float(np.min(rho_tab)) > 1e-30)
     current_time = 0.0
     done = 0
+    custom_generation = None                                     # compiled at its first use, then reused every step
     for step in range(1, total_steps + 1):                       # solver.py:1454-1494
         final = step > full_steps
         dt_step = rem if final else dt
@@ -597,7 +632,10 @@ def run_2d_crank_nicolson(
                 if on:
                     eng.add_constant(state, dt_step * float(external_generation.pulse_rate))
             elif gen_mode == "custom":
-                g_ext = evaluate_external_generation(external_generation, E_bins, n, current_time, mask)
+                if custom_generation is None:
+                    custom_generation = _CustomGeneration(external_generation, mask)
+                g_ext = evaluate_external_generation(external_generation, E_bins, n, current_time, mask,
+                                                     _compiled=custom_generation)
                 if g_ext is not None:
                     eng.add_scaled(state, eng.upload_packed(g_ext), dt_step)
         guarded = False

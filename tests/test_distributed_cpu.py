@@ -91,9 +91,10 @@ def test_halo_step_bound_and_stage_sequence():
     assert halo_steps_bound(0.1) > halo_steps_bound(0.3) > halo_steps_bound(0.75) > halo_steps_bound(1.5) >= 1
     assert halo_steps_bound(5.0) == 0
     seq = list(overlap_stages(10, 4, 0))
-    assert seq == [("steps", 4), ("exchange", 0), ("exchange", 1), ("steps", 4), ("exchange", 0), ("exchange", 1), ("steps", 2)]
-    assert list(overlap_stages(3, 4, 2)) == [("steps", 2), ("exchange", 0), ("exchange", 1), ("steps", 1)]
-    assert list(overlap_stages(2, 4, 4)) == [("exchange", 0), ("exchange", 1), ("steps", 2)]
+    R = ("refresh", None)                # ONE round of messages per refresh (sides and diagonals together)
+    assert seq == [("steps", 4), R, ("steps", 4), R, ("steps", 2)]
+    assert list(overlap_stages(3, 4, 2)) == [("steps", 2), R, ("steps", 1)]
+    assert list(overlap_stages(2, 4, 4)) == [R, ("steps", 2)]
 
 
 @pytest.mark.parametrize("py,px,gny,gnx", [(1, 2, 70, 192), (2, 1, 192, 70), (2, 2, 192, 200), (1, 3, 64, 256)])
@@ -191,3 +192,77 @@ def test_decomposed_steps_over_gloo_world_size_2(tmp_path, py, px):
         got[:, j0:j0 + ny, i0:i0 + nx] = np.load(tmp_path / f"overlap_{r}.npy")
     want = _oracle_steps(mask, edges, bcs, dx, dt, D, u0, 5)
     assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 1e-13
+
+
+def test_refresh_windows_cover_the_halos_exactly_once_and_pair_up_between_ranks():
+    """One refresh round (`OverlapBlock.windows`): on every rank of a 3 x 3 grid the receive windows tile the halo ring
+    without gaps or overlaps, every send window lies inside the own cells, and what rank A sends to B has the shape of
+    what B receives from A (sides: strips, diagonals: H x H corner blocks)."""
+    from qpsim_amd.distributed import OverlapBlock
+    gny, gnx, H = 3 * 128, 3 * 192, 64
+    blocks = {r: OverlapBlock(BlockTopology(gny, gnx, 3, 3, r), 2, 0.3, halo=H) for r in range(9)}
+    for r, b in blocks.items():
+        cover = np.zeros((b.ey, b.ex), dtype=int)
+        for peer, (sr, sc, nr, nc), (rr, rc, nr2, nc2) in b.windows():
+            assert (nr, nc) == (nr2, nc2)
+            assert b.hu <= sr and sr + nr <= b.hu + b.ny and b.hl <= sc and sc + nc <= b.hl + b.nx
+            cover[rr:rr + nr, rc:rc + nc] += 1
+            back = [w for w in blocks[peer].windows() if w[0] == r]
+            assert len(back) == 1 and back[0][2][2:] == (nr, nc) and back[0][1][2:] == (nr, nc)
+        own = np.zeros_like(cover)
+        own[b.hu:b.hu + b.ny, b.hl:b.hl + b.nx] = 1
+        assert np.array_equal(cover, 1 - own)
+    centre = blocks[4]
+    assert len(centre.windows()) == 8 and centre.refresh_bytes == 8 * 2 * (2 * H * (128 + 192) + 4 * H * H)
+    assert len(blocks[0].windows()) == 3
+
+
+def test_halo_cost_model_prefers_wide_halos_only_when_refreshes_are_expensive():
+    from qpsim_amd.distributed import halo_cost_model
+    topo = BlockTopology(8192, 8192, 2, 4, 0)
+    cheap = halo_cost_model(topo, 0.3, refresh_latency_us=20.0)
+    dear = halo_cost_model(topo, 0.3, refresh_latency_us=400.0)
+    assert cheap["choice"] == 64 and dear["choice"] == 128
+    t = dear["table"]
+    assert t[64]["steps_per_refresh"] == halo_steps_bound(0.3, 64, cap=256) and t[128]["steps_per_refresh"] > 3 * t[64]["steps_per_refresh"]
+    assert t[64]["cells"] == (4096 + 64) * (2048 + 128) and t[128]["cells"] == (4096 + 128) * (2048 + 256)
+    assert 64 not in halo_cost_model(topo, 5.0)["table"]                     # a wider halo carries stiffer steps ...
+    assert halo_cost_model(topo, 500.0)["choice"] is None                    # ... but not any
+    assert 128 not in halo_cost_model(BlockTopology(128, 512, 2, 4, 0), 0.3)["table"]     # 64-row blocks cannot carry 128
+
+
+def _gloo_2x2_worker(rank, world, port, gny, gnx, nsteps, out_dir):
+    for p in (str(ROOT), str(ROOT / "quasiparticle-physics-simulation_amd"), str(ROOT / "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from qpsim_amd.distributed import measure_refresh
+        mask, edges, bcs, dx, dt, D, bc_diag, bc_src, u0 = _problem(gny, gnx)
+        topo = BlockTopology(gny, gnx, 2, 2, rank)
+        ob = NumpyOverlapBlock(topo, dx, dt, D, SIDE_BC, steps_per_exchange=2)
+        ob.set_field(u0)
+        overlap_adi_steps(ob, TorchDistTransport(), nsteps)
+        np.save(os.path.join(out_dir, f"overlap_{rank}.npy"), ob.get_field())
+        stages = measure_refresh(ob, TorchDistTransport(), reps=2)      # refreshing again changes nothing
+        assert stages["refresh_us"] > 0 and stages["bytes_received"] == ob.refresh_bytes
+        np.save(os.path.join(out_dir, f"again_{rank}.npy"), ob.get_field())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_four_processes_2x2_refresh_sides_and_corners_in_one_round_over_gloo(tmp_path):
+    """world_size 4 over gloo, 2 x 2 blocks: every rank has two side neighbours and one diagonal neighbour, all served by
+    one `batch_isend_irecv` per refresh (the corner block no longer rides on a second, ordered round)."""
+    gny, gnx, nsteps = 192, 256, 5
+    mp.spawn(_gloo_2x2_worker, args=(4, _free_port(), gny, gnx, nsteps, str(tmp_path)), nprocs=4, join=True)
+    mask, edges, bcs, dx, dt, D, bc_diag, bc_src, u0 = _problem(gny, gnx)
+    want = _oracle_steps(mask, edges, bcs, dx, dt, D, u0, nsteps)
+    for tag in ("overlap", "again"):
+        got = np.zeros_like(u0)
+        for r in range(4):
+            j0, i0, ny, nx = BlockTopology(gny, gnx, 2, 2, r).block
+            got[:, j0:j0 + ny, i0:i0 + nx] = np.load(tmp_path / f"{tag}_{r}.npy")
+        assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 1e-13, tag

@@ -248,3 +248,47 @@ def test_fine_tile_block_mapping_is_a_bijection_that_keeps_super_tiles_on_one_xc
         assert len(seen) == 2 * ns
         for S in range(8 * (ns // 8)):
             assert seen[(S, 0)] % 8 == seen[(S, 1)] % 8 == S % 8
+
+
+def test_external_generation_matches_reference_and_every_strategy_agrees():
+    """`solver.evaluate_external_generation` against the reference's own outputs (host_side.npz: constant, pulse inside /
+    at the end of / before its window, a vectorisable and a scalar custom body), and its three evaluation strategies
+    (one broadcast call, per bin, per cell) against each other."""
+    from qpsim_amd.safe_eval import expression_is_elementwise
+    from qpsim_amd.solver import _CustomGeneration, evaluate_external_generation
+    z, meta = _z("host_side.npz")
+    mask, E = z["ic_mask"], z["ic_E"]
+    n = int(mask.sum())
+    for nm in ("const", "pulse_in", "pulse_end", "pulse_before", "custom_vec", "custom_scalar"):
+        spec = ExternalGenerationSpec(**meta[f"gen_{nm}"]["spec"])
+        got = evaluate_external_generation(spec, E, n, meta[f"gen_{nm}"]["t"], mask)
+        assert got.shape == (E.size, n) and np.allclose(got, z[f"gen_{nm}"], rtol=1e-15, atol=0), nm
+    assert evaluate_external_generation(ExternalGenerationSpec(mode="none"), E, n, 0.0, mask) is None
+
+    arrays = ("E", "x", "y")
+    for body, elementwise in (("params['g'] * np.exp(-E / 400.0) * (1 + x) * (t < 1.0)", True),
+                              ("np.where(x > 0.5, E, 2 * y)", True), ("3e-9", True), ("1.0 if t < 1 else 0.0", True),
+                              ("1.0 if E > 300 else 0.0", False), ("(E > 300) and (t < 1)", False), ("x[0] + E", False),
+                              ("x.size * E", False), ("len(x) * E", False), ("math.exp(-E / 400.0)", False),
+                              ("np.arange(params['nx']) * E", True), ("np.zeros_like(x) + E", False), ("0.2 < x < 0.8", False)):
+        assert expression_is_elementwise(body, array_variables=arrays) is elementwise, body
+
+    # an expression only the per-bin strategy can vectorise (scalar E in a conditional), and one that needs the per-cell loop
+    for body in ("(1e-8 if E > 300 else 2e-8) * (1 + x)", "math.exp(-E / 400.0) * 1e-8 * (1 + math.sin(y))"):
+        spec = ExternalGenerationSpec(mode="custom", custom_body=body)
+        gen = _CustomGeneration(spec, mask)
+        want = gen._per_cell(np.asarray(E, dtype=float), 0.3, (E.size, n))
+        assert np.allclose(evaluate_external_generation(spec, E, n, 0.3, mask), want, rtol=1e-15, atol=0)
+    spec = ExternalGenerationSpec(mode="custom", custom_body="1e-8 * np.exp(-E / 400.0) * np.maximum(x - y, 0.0) * (t < 1)")
+    gen = _CustomGeneration(spec, mask)
+    shape = (E.size, n)
+    a, b, c = (f(np.asarray(E, dtype=float), 0.3, shape) for f in (gen._on_grid, gen._per_bin, gen._per_cell))
+    assert np.allclose(a, b, rtol=1e-15, atol=0) and np.allclose(b, c, rtol=1e-15, atol=0)
+
+    # the reference's messages (solver.py:889-902, :944-947)
+    with pytest.raises(ValueError, match="produced negative values"):
+        evaluate_external_generation(ExternalGenerationSpec(mode="custom", custom_body="-1.0"), E, n, 0.0, mask)
+    with pytest.raises(ValueError, match="produced non-finite values"):
+        evaluate_external_generation(ExternalGenerationSpec(mode="custom", custom_body="np.log(x - 1)"), E, n, 0.0, mask)
+    with pytest.raises(Exception):      # 3 values per bin: the vectorised attempts refuse, the per-cell loop cannot convert
+        evaluate_external_generation(ExternalGenerationSpec(mode="custom", custom_body="np.arange(3) * 1.0"), E, n, 0.0, mask)
