@@ -219,6 +219,9 @@ def strong_scaling_record(args, dev, world: int, rank: int, stage: dict | None =
     def at(name: str) -> None:
         stage["name"] = f"strong: {name}"
 
+    if os.environ.get("QPSIM_BENCH_HANG_RANK") == str(rank):      # rehearsal of the watchdog only: this rank never arrives
+        at("rehearsal: this rank hangs on purpose (QPSIM_BENCH_HANG_RANK)")
+        time.sleep(1e6)
     at("1-rank reference run on rank 0")
     t1 = torch.zeros(1, dtype=torch.float64, device=dev)
     if rank == 0:

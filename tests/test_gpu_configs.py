@@ -392,3 +392,49 @@ def test_rect_combine_equals_the_general_stencil(ny, nx):
         scale = float(b.abs().max())
         assert float((a - b).abs().max()) <= 4e-15 * scale
         assert float(norm.item()) == float(a.abs().max())
+
+
+def test_fused_guard_workspace_holds_every_partial_the_kernels_write():
+    """160 x 213 = 34080 cells (> 32768, and 34080 % 128 = 32 lies in [1, 64]): the register kernels launch
+    ceil(ncell / 128) blocks of two waves and every wave writes a partial - one more than ceil(ncell / 64).  The workspace
+    is allocated at EXACTLY `qp_collision_guard_workspace_bytes` with a canary behind it; the fused result must equal the
+    separate reduction and the canary must survive."""
+    import ctypes as C
+    import torch
+    from qpsim_amd import _hip
+    from qpsim_amd import tables as T
+    from qpsim_amd.engine import CompiledGeometry, Engine, link_flags
+    ny, nx, ne = 160, 213, 12
+    ncell = ny * nx
+    assert ncell > 32768 and 1 <= ncell % 128 <= 64
+    mask = np.ones((ny, nx), dtype=bool)
+    z = np.zeros(mask.shape)
+    eng = Engine(CompiledGeometry(mask, 1.0, link_flags(mask), z, z, z, z))
+    lib = eng.lib
+    nbytes = int(lib.qp_collision_guard_workspace_bytes(ncell))
+    assert nbytes >= 24 * (2 * ((ncell + 127) // 128) + 512)
+    E, dE = T.build_energy_grid(180.0, 1.0, 3.0, ne)
+    om, idx_d, idx_s, sg = T.build_phonon_frequency_map(E)
+    rho = T.dynes_density_of_states(E, 180.0, 0.1)
+    kr, ks = T.recombination_kernel_base(E, 180.0, 500.0, 1.2), T.scattering_kernel_base(E, 180.0, 400.0, 1.2)
+    tab = eng.make_collision_tables(kr[None], ks[None], rho[None], idx_d, idx_s, sg)
+    assert tab["kernel"] == "register"
+    rng = np.random.default_rng(4)
+    state = rng.random((ne, ncell)) * rho[:, None] * 0.5
+    state[:, -1] = 0.93 * rho                      # the maximum sits in the very last cell: the partial of the LAST wave
+    ph = T.thermal_phonon_occupation(om, 0.3)[:, None] * (0.5 + rng.random((om.size, ncell)))
+    s_in, p_dev = eng.upload_packed(state), eng.upload_packed(ph)
+    s_out = eng.empty(ne, ncell)
+    pad = 4096
+    raw = torch.full((nbytes + pad,), 0xA5, dtype=torch.uint8, device=eng.device)
+    vals = torch.zeros(2, dtype=torch.float64, device=eng.device)
+    idx = torch.zeros(2, dtype=torch.int64, device=eng.device)
+    _hip.check(lib.qp_collision_step_guarded(C.byref(tab["struct"]), int(eng.d_flags.data_ptr()), ncell,
+                                             int(s_in.data_ptr()), int(s_out.data_ptr()), int(p_dev.data_ptr()), 0,
+                                             float(dE), 0.2, 1, 1, 1, 1e-18, int(raw.data_ptr()), int(vals.data_ptr()),
+                                             int(idx.data_ptr()), eng.stream), "qp_collision_step_guarded")
+    torch.cuda.synchronize()
+    assert bool((raw[nbytes:] == 0xA5).all()), "the fused guard wrote past its workspace"
+    mx, top, forb = eng.pauli_stats(s_out, tab, 1e-18)
+    assert float(vals[0]) == mx and int(idx[0]) == top[0] * ncell + top[1] and int(idx[1]) == -1 and forb is None
+    assert top[1] == ncell - 1

@@ -180,3 +180,90 @@ def test_coupled_step_on_a_decomposed_grid_matches_the_single_domain_run():
         err = float((got - ref[:, j0:j0 + ny, i0:i0 + nx]).abs().max()) / scale
         assert err < 1e-13, (w.topo.rank, err)
     assert ranks[0].inner.max_occ > 0.0
+
+
+@pytest.mark.parametrize("nfield,ey,ex", [(1, 192, 256), (3, 130, 71), (2, 64, 64)])
+def test_halo_pack_kernel_moves_every_window_both_ways(nfield, ey, ex):
+    """`qp_halo_pack` (all windows of a refresh in one launch; 16-byte path for even geometry, 8-byte path otherwise) against
+    the slice copies of the device-agnostic `OverlapBlock.pack / unpack`."""
+    import ctypes as C
+    import torch
+    from qpsim_amd import _hip
+    lib = _hip.load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rng = np.random.default_rng(ey + ex)
+    rects = [(0, 0, 7, 9), (ey - 5, ex - 11, 5, 11), (3, 2, ey - 6, 4), (1, ex - 8, 2, 8), (ey // 2, 0, 1, ex),
+             (0, ex // 2, ey, 1), (8, 8, 16, 16), (ey - 1, 0, 1, 1)]
+    u = torch.as_tensor(rng.random((nfield, ey, ex)), device=dev)
+    total = sum(nfield * r[2] * r[3] for r in rects)
+    buf = torch.full((total,), -1.0, dtype=torch.float64, device=dev)
+    arr = (C.c_int32 * (4 * len(rects)))(*[v for r in rects for v in r])
+    stream = int(torch.cuda.current_stream(dev).cuda_stream)
+    _hip.check(lib.qp_halo_pack(int(u.data_ptr()), nfield, ey, ex, arr, len(rects), 0, int(buf.data_ptr()), stream), "pack")
+    want = torch.cat([u[:, r:r + nr, c:c + nc].reshape(-1) for r, c, nr, nc in rects])
+    assert torch.equal(buf, want)
+    fresh = torch.as_tensor(rng.random(total), device=dev)
+    target = u.clone()
+    _hip.check(lib.qp_halo_pack(int(target.data_ptr()), nfield, ey, ex, arr, len(rects), 1, int(fresh.data_ptr()), stream),
+               "unpack")
+    ref, off = u.clone(), 0
+    for r, c, nr, nc in rects:              # later windows overwrite earlier ones where they overlap, in window order
+        n = nfield * nr * nc
+        ref[:, r:r + nr, c:c + nc] = fresh[off:off + n].view(nfield, nr, nc)
+        off += n
+    # overlapping windows are written by different blocks of one launch: compare where exactly one window covers a cell
+    cover = torch.zeros((ey, ex), dtype=torch.int32, device=dev)
+    for r, c, nr, nc in rects:
+        cover[r:r + nr, c:c + nc] += 1
+    once = (cover <= 1)[None].expand_as(ref)
+    assert torch.equal(target[once], ref[once])
+    with pytest.raises(_hip.QPHipError, match="window outside the block"):
+        bad = (C.c_int32 * 4)(0, 0, ey + 1, 1)
+        _hip.check(lib.qp_halo_pack(int(u.data_ptr()), nfield, ey, ex, bad, 1, 0, int(buf.data_ptr()), stream), "pack")
+
+
+def _coupled_2x2_worker(rank, world, port, N, steps, out_dir):
+    for p in (str(ROOT), str(ROOT / "quasiparticle-physics-simulation_amd"), str(ROOT / "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    from qpsim_amd.bench_workloads import OverlapDecomposedWorkload
+    from qpsim_amd.distributed import measure_refresh
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        w = OverlapDecomposedWorkload(N, dev, coupled=True, steps_per_exchange=4)
+        assert (w.topo.py, w.topo.px) == (2, 2) and w.block.steps_per_exchange == 2 and len(w.block.windows()) == 3
+        w.run(steps)
+        torch.cuda.synchronize()
+        np.save(os.path.join(out_dir, f"own_{rank}.npy"), w.block.own.cpu().numpy())
+        st = measure_refresh(w.block, w.transport, reps=2, sync=torch.cuda.synchronize)
+        assert st["refresh_us"] > 0
+    finally:
+        dist.destroy_process_group()
+
+
+def test_four_processes_2x2_coupled_step_over_gloo(tmp_path):
+    """Four real processes on the one GPU (gloo transport, strips staged through the host), 2 x 2 blocks, the COUPLED step
+    (collision half-steps + ADI, NE = 12) with the one-round refresh (two side strips + one corner block per rank, packed
+    by `qp_halo_pack`) - own cells equal to the undecomposed run of the same steps."""
+    import torch
+    import torch.multiprocessing as mp
+    from qpsim_amd.bench_workloads import CoupledWorkload, _global_field
+    from qpsim_amd.distributed import BlockTopology
+    from test_distributed_cpu import _free_port
+    N, steps = 256, 5
+    mp.spawn(_coupled_2x2_worker, args=(4, _free_port(), N, steps, str(tmp_path)), nprocs=4, join=True)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    whole = CoupledWorkload(N, dev, init_occupation=_global_field(torch, 0, 0, N, N, dev).reshape(-1))
+    whole.run(steps)
+    torch.cuda.synchronize()
+    ref = whole.state.view(whole.ne, N, N).cpu().numpy()
+    for r in range(4):
+        j0, i0, ny, nx = BlockTopology(N, N, 2, 2, r).block
+        got = np.load(tmp_path / f"own_{r}.npy")
+        assert np.max(np.abs(got - ref[:, j0:j0 + ny, i0:i0 + nx])) / np.max(np.abs(ref)) < 1e-13, r
