@@ -133,6 +133,11 @@ bool collision_fast_dispatch(int ne, const double* kr0, const double* ks0, const
                              double* sout, double* ph, double dE, double dt, int en_r, int en_s, int upd,
                              PauliPartial* guard, double guard_floor, bool* guard_done, hipStream_t stream);
 
+bool collision_onepass_dispatch(const qp_collision_tables& tb, double* stash, const uint8_t* flags, long ncell,
+                                const double* sin_, double* sout, double* ph, double dE, double dt, bool s, bool r, bool u,
+                                hipStream_t stream);
+
+int collision_onepass_supported(int ne);
 int collision_fast_supported(int ne);
 int collision_fast_classes_supported(int ne);
 bool collision_fast_dispatch_classes(int ne, const double* rho, const int* cls, const double* gap_sq, const double* kr_amp,
@@ -185,6 +190,14 @@ static int collision_step_impl(const qp_collision_tables* t, const uint8_t* flag
   // without scratch only the variants that never write phonons qualify
   const bool shared_ok = !(t->flags & QP_COLL_SHARED_BINS) || ph_scratch ||
                          !(update_phonons && enable_recombination && enable_scattering && t->kr0 && t->ks0);
+  // 32 <= ne <= 64 with the diagonal-major tables: one launch instead of the three of the split path
+  if (t->diag_bin && t->nclass == 1 && qp::collision_onepass_supported(t->ne) && !(t->flags & (QP_COLL_FORCE_GENERIC | QP_COLL_FORCE_WAVE)) &&
+      shared_ok && ncell < (1L << 28) &&
+      qp::collision_onepass_dispatch(*t, ph_scratch, flags, (long)ncell, state_in, state_out, phonon, dE, dt,
+                                     enable_scattering && t->ks0, enable_recombination && t->kr0,
+                                     update_phonons && ((enable_scattering && t->ks0) || (enable_recombination && t->kr0)),
+                                     (hipStream_t)stream))
+    return qp::check_launch("qp_collision_step(one pass)");
   if (t->diag_bin && t->nclass == 1 && !(t->flags & (QP_COLL_FORCE_GENERIC | QP_COLL_FORCE_WAVE)) && shared_ok &&
       qp::collision_fast_dispatch(t->ne, t->kr0, t->ks0, t->rho, t->diag_bin, t->anti_bin, ph_scratch, flags, (long)ncell,
                                   state_in, state_out, phonon, dE, dt, enable_recombination, enable_scattering,
@@ -308,6 +321,8 @@ extern "C" int qp_euler_collision(int32_t ne, int64_t ncell, const double* state
 
 // 1 when the register-resident collision kernel is instantiated for this number of energy bins
 extern "C" int qp_collision_register_kernel_available(int32_t ne) { return qp::collision_fast_supported(ne); }
+
+extern "C" int qp_collision_onepass_available(int32_t ne) { return qp::collision_onepass_supported(ne); }
 
 // 2nd bit: the gap-class variant (separable kernel tables, qp_collision_tables::gap_sq ...) exists as well
 extern "C" int qp_collision_register_kernel_classes(int32_t ne) { return qp::collision_fast_classes_supported(ne); }

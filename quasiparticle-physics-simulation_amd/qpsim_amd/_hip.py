@@ -38,7 +38,8 @@ class CollisionTables(_SizedStructure):
     _fields_ = [("struct_size", C.c_uint32), ("ne", C.c_int32), ("nw", C.c_int32), ("nclass", C.c_int32),
                 ("kr0", c_dp), ("ks0", c_dp), ("rho", c_dp), ("idx_diff", c_dp), ("idx_sum", c_dp),
                 ("sign", c_dp), ("cls", c_dp), ("diag_bin", c_dp), ("anti_bin", c_dp), ("flags", C.c_uint32),
-                ("gap_sq", c_dp), ("kr_amp", c_dp), ("ks_amp", c_dp), ("pair_inv", c_dp)]
+                ("gap_sq", c_dp), ("kr_amp", c_dp), ("ks_amp", c_dp), ("pair_inv", c_dp),
+                ("ks0_diag", c_dp), ("kr0_anti2", c_dp)]
 
 
 class RectPlan(C.Structure):
@@ -103,6 +104,7 @@ SIGNATURES = {
     "qp_nan_pad": (C.c_int, [c_dp, C.c_int64, C.c_int32, c_dp, C.c_double, c_dp, c_dp]),
     "qp_collision_register_kernel_available": (C.c_int, [C.c_int32]),
     "qp_collision_register_kernel_classes": (C.c_int, [C.c_int32]),
+    "qp_collision_onepass_available": (C.c_int, [C.c_int32]),
     "qp_adi_tile_plan_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.POINTER(C.c_double), c_dp, c_dp,
                                           c_dp, c_dp, c_dp, C.POINTER(C.POINTER(TilePlan))]),
     "qp_adi_tile_plan_create_var": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_double, c_dp, c_dp, c_dp, c_dp, c_dp,

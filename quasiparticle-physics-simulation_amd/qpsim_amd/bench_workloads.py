@@ -316,7 +316,11 @@ class CoupledWorkload:
         pairs = self.ne * self.ne
         flops = 26.0 * pairs * self.npix               # ~26 NE^2 flop per pixel-update
         tflops = flops / per_call / 1e12
+        import os
+        onepass = (self.tab.get("ks0_diag") is not None or self.tab.get("kr0_anti2") is not None) \
+            and os.environ.get("QPSIM_COLL_ONEPASS", "1") != "0"
         kernel = {"register": "collision_diag_kernel" if self.ne < 32 else
+                  "collision_onepass_kernel (one launch, tables staged in LDS)" if onepass else
                   "collision_range_kernel x2 + collision_phonon_kernel (one call)", "wave": "collision_wave_kernel",
                   "generic": "collision_generic_kernel"}[self.tab["kernel"]]
         traffic, source = self._pmc_traffic(), None

@@ -198,6 +198,30 @@ def structured_bin_maps(idx_diff, idx_sum, sign, allow_shared: bool = False):
     return diag.astype(np.int32), anti.astype(np.int32)
 
 
+def diagonal_major(table: np.ndarray) -> np.ndarray:
+    """[..., ne, ne] -> [..., ne, ne] with out[k, i] = table[i, i - k] for k <= i < ne, 0 elsewhere: row k holds diagonal k
+    (the pairs with E_i - E_j = k dE) indexed by the higher bin - what a sweep along that diagonal reads is contiguous."""
+    t = np.asarray(table, dtype=np.float64)
+    ne = t.shape[-1]
+    out = np.zeros_like(t)
+    for k in range(ne):
+        i = np.arange(k, ne)
+        out[..., k, i] = t[..., i, i - k]
+    return out
+
+
+def antidiagonal_major(table: np.ndarray, scale: float = 1.0) -> np.ndarray:
+    """[..., ne, ne] -> [..., 2 ne - 1, ne] with out[m, i] = scale * table[i, m - i] for 0 <= m - i < ne, 0 elsewhere: row m
+    holds anti-diagonal m (the pairs with E_i + E_j fixed) indexed by one of its bins."""
+    t = np.asarray(table, dtype=np.float64)
+    ne = t.shape[-1]
+    out = np.zeros(t.shape[:-2] + (2 * ne - 1, ne))
+    for m in range(2 * ne - 1):
+        i = np.arange(max(0, m - ne + 1), min(ne, m + 1))
+        out[..., m, i] = scale * t[..., i, m - i]
+    return out
+
+
 def tag_merged_bins(diag, anti):
     """(diag, anti, n_merged): entries of a phonon bin fed by both a diagonal k >= 1 and an anti-diagonal m get
     (slot + 1) << 16 added, slot numbering the merged bins (what the register collision kernels expect, qpsim_hip.h)."""
@@ -860,10 +884,18 @@ class Engine:
                        "register" if (kernel == "auto" and structure is not None and (nclass == 1 or classes_ok)
                                       and bool(self.lib.qp_collision_register_kernel_available(ne))) else "wave")
         h["fast"] = h["kernel"] != "generic"      # no accumulator planes needed
+        # one-pass kernel (ne = 50): the kernel tables once more in (anti)diagonal-major order (qpsim_hip.h)
+        h["ks0_diag"] = h["kr0_anti2"] = None
+        if (h["kernel"] == "register" and nclass == 1 and symmetric and bool(self.lib.qp_collision_onepass_available(ne))):
+            if ks0 is not None:
+                h["ks0_diag"] = up(diagonal_major(np.asarray(ks0).reshape(ne, ne)), np.float64)
+            if kr0 is not None:
+                h["kr0_anti2"] = up(antidiagonal_major(np.asarray(kr0).reshape(ne, ne), 2.0), np.float64)
         h["struct"] = _hip.CollisionTables.make(ne, nw, nclass, _ptr(h["kr0"]), _ptr(h["ks0"]), _ptr(h["rho"]),
                                            _ptr(h["idx_diff"]), _ptr(h["idx_sum"]), _ptr(h["sign"]), _ptr(h["cls"]),
                                            _ptr(h["diag_bin"]), _ptr(h["anti_bin"]), flag_bits,
-                                           _ptr(h["gap_sq"]), _ptr(h["kr_amp"]), _ptr(h["ks_amp"]), _ptr(h["pair_inv"]))
+                                           _ptr(h["gap_sq"]), _ptr(h["kr_amp"]), _ptr(h["ks_amp"]), _ptr(h["pair_inv"]),
+                                           _ptr(h["ks0_diag"]), _ptr(h["kr0_anti2"]))
         return h
 
     def collide(self, tables, state, state_out, phonon, dE, dt, en_r, en_s, update_phonons):

@@ -438,3 +438,43 @@ def test_fused_guard_workspace_holds_every_partial_the_kernels_write():
     mx, top, forb = eng.pauli_stats(s_out, tab, 1e-18)
     assert float(vals[0]) == mx and int(idx[0]) == top[0] * ncell + top[1] and int(idx[1]) == -1 and forb is None
     assert top[1] == ncell - 1
+
+
+@pytest.mark.parametrize("combo", [(True, True, True), (True, True, False), (True, False, True), (False, True, True)])
+def test_one_pass_ne50_kernel_equals_the_split_kernels_on_a_ragged_masked_grid(monkeypatch, combo):
+    """NE = 50 (the reference's default `num_energy_bins`): the one-launch kernel (256-thread blocks, tables staged in LDS,
+    lanes past the end of the grid and cells outside the mask inside a block) against the three-launch split path on the
+    same inputs - quasiparticle planes to rounding (q = max(rho - n, 0) on both), phonon planes within the conditioning
+    bound of the reference's (e^x - 1)/x (the 80-bit test above prices it), masked cells passed through untouched."""
+    from qpsim_amd import tables as T
+    from qpsim_amd.engine import CompiledGeometry, Engine, link_flags
+    en_r, en_s, upd = combo
+    ne = 50
+    rng = np.random.default_rng(17)
+    mask = rng.random((23, 37)) > 0.2                     # 851 cells: 4 blocks of 256 threads, the last one ragged
+    z = np.zeros(mask.shape)
+    eng = Engine(CompiledGeometry(mask, 1.0, link_flags(mask), z, z, z, z))
+    assert eng.ncell % 256 != 0 and bool(eng.lib.qp_collision_onepass_available(ne))
+    n = int(mask.sum())
+    E, dE = T.build_energy_grid(180.0, 1.0, 10.0, ne)
+    om, idx_d, idx_s, sg = T.build_phonon_frequency_map(E)
+    rho = T.dynes_density_of_states(E, 180.0, 0.1)
+    kr, ks = T.recombination_kernel_base(E, 180.0, 500.0, 1.2), T.scattering_kernel_base(E, 180.0, 400.0, 1.2)
+    state = rng.random((ne, n)) * rho[:, None] * rng.choice([1e-5, 1e-2, 0.5, 0.95], size=n)[None, :]
+    ph = T.thermal_phonon_occupation(om, 0.3)[:, None] * (0.5 + rng.random((om.size, n)))
+    tab = eng.make_collision_tables(kr[None], ks[None], rho[None], idx_d, idx_s, sg)
+    assert tab["kernel"] == "register" and tab["ks0_diag"] is not None and tab["kr0_anti2"] is not None
+    outs = {}
+    for onepass in ("1", "0"):
+        monkeypatch.setenv("QPSIM_COLL_ONEPASS", onepass)
+        s_in, p_dev = eng.upload_packed(state), eng.upload_packed(ph)
+        s_out = eng.empty(ne, eng.ncell)
+        s_out.fill_(-7.0)
+        eng.collide(tab, s_in, s_out, p_dev, dE, 0.37, en_r, en_s, upd)
+        outs[onepass] = (eng.download_packed(s_out), eng.download_packed(p_dev), s_out.cpu().numpy(), p_dev.cpu().numpy())
+    assert rel_err(outs["1"][0], outs["0"][0]) < 1e-13
+    assert rel_err(outs["1"][1], outs["0"][1]) < (1e-10 if upd else 1e-300)
+    hole = ~mask.reshape(-1)
+    assert np.all(outs["1"][2][:, hole] == 0.0) and np.all(outs["1"][3][:, hole] == 0.0)
+    if not upd:
+        assert np.array_equal(outs["1"][1], ph)
