@@ -144,7 +144,8 @@ typedef struct qp_collision_tables {
   const double* ks_amp;
   const double* pair_inv;
   /* Optional, for the ONE-PASS register kernel (qp_collision_onepass_available(ne); one gap class): one launch that reads
-   * n and every phonon plane's old value from HBM once, where ne >= 32 otherwise runs three launches.  Its phonon phase
+   * the old quasiparticle planes once and sweeps the phonon planes once per target block, where ne >= 32 otherwise runs
+   * three launches.  Its phonon phase
    * walks the pairs (anti)diagonal by (anti)diagonal and wants the kernel values of a diagonal contiguous:
    *   ks0_diag  [ne][ne]      ks0_diag [k*ne + i] =     ks0[i][i-k]   for k <= i < ne,      0 elsewhere (k = 0..ne-1)
    *   kr0_anti2 [2ne-1][ne]   kr0_anti2[m*ne + i] = 2 * kr0[i][m-i]   for 0 <= m-i < ne,    0 elsewhere (m = 0..2ne-2)
@@ -186,8 +187,8 @@ int qp_collision_step_guarded(const qp_collision_tables* t, const uint8_t* flags
 /* 1 when qp_collision_step has a register-resident kernel for `ne` energy bins (structured, unshared bin maps and one gap
  * class are the other conditions); other sizes <= 64 run the one-wave-per-pixel kernel, larger ones the generic kernel. */
 int qp_collision_register_kernel_available(int32_t ne);
-/* 1 when the one-pass kernel (ks0_diag / kr0_anti2 above) is instantiated for `ne` energy bins (ne = 50, the reference's
- * default num_energy_bins, solver.py:1012). */
+/* 1 when the one-pass kernel (ks0_diag / kr0_anti2 above) is instantiated for `ne` energy bins: ne = 32, 40 and 50 (the
+ * reference's default num_energy_bins, solver.py:1012). */
 int qp_collision_onepass_available(int32_t ne);
 /* 1 when the register-resident kernel also has its gap-class variant for `ne` (single-pass sizes: ne <= 16, 18, 20, 24, 30). */
 int qp_collision_register_kernel_classes(int32_t ne);

@@ -554,8 +554,8 @@ class Engine:
         """Same frames, but the call only ENQUEUES: the NaN padding runs on the compute stream into a staging buffer, the
         device-to-host copy runs on a side stream into pinned memory, and the compute stream goes on with the next time
         step.  ``ticket.result()`` waits for that copy and returns the frames as a fresh NumPy array.  A small ring of
-        staging / pinned buffer pairs is reused; taking a slot whose previous ticket is still open completes that ticket
-        first (its copy has had a whole store interval to finish)."""
+        staging / pinned buffer pairs is reused (one ring for single planes, one for plane sets); taking a slot whose
+        previous ticket is still open completes that ticket first (its copy has had a whole store interval to finish)."""
         torch = self.torch
         planes = planes.reshape(-1, self.ncell)
         n = planes.shape[0]
@@ -563,10 +563,16 @@ class Engine:
         numel = int(np.prod(shape))
         if not hasattr(self, "_dl_slots"):
             self._dl_stream = torch.cuda.Stream(device=self.device)
-            self._dl_slots = [{"dev": None, "host": None, "ticket": None} for _ in range(3)]
-            self._dl_next = 0
-        slot = self._dl_slots[self._dl_next]
-        self._dl_next = (self._dl_next + 1) % len(self._dl_slots)
+            # Two rings: a store point of a full-physics run enqueues up to four downloads (integrated frame, state, phonon
+            # planes, phonon sum) - two of one plane, two of NE / Nw planes.  Each ring holds two store points' worth of its
+            # size class, so a slot is recycled only after a whole store interval (and small frames do not grow to the
+            # size of the state: 2 x 2 large staging pairs instead of 3 of everything).
+            self._dl_slots = {cls: [{"dev": None, "host": None, "ticket": None} for _ in range(4)] for cls in ("small", "large")}
+            self._dl_next = {"small": 0, "large": 0}
+        ring_name = "small" if n <= 1 else "large"
+        ring = self._dl_slots[ring_name]
+        slot = ring[self._dl_next[ring_name]]
+        self._dl_next[ring_name] = (self._dl_next[ring_name] + 1) % len(ring)
         if slot["ticket"] is not None:
             slot["ticket"].result()                    # frees the slot (keeps the frames inside the ticket)
         if slot["dev"] is None or slot["dev"].numel() < numel:
@@ -884,7 +890,7 @@ class Engine:
                        "register" if (kernel == "auto" and structure is not None and (nclass == 1 or classes_ok)
                                       and bool(self.lib.qp_collision_register_kernel_available(ne))) else "wave")
         h["fast"] = h["kernel"] != "generic"      # no accumulator planes needed
-        # one-pass kernel (ne = 50): the kernel tables once more in (anti)diagonal-major order (qpsim_hip.h)
+        # one-pass kernel (ne = 32, 40, 50): the kernel tables once more in (anti)diagonal-major order (qpsim_hip.h)
         h["ks0_diag"] = h["kr0_anti2"] = None
         if (h["kernel"] == "register" and nclass == 1 and symmetric and bool(self.lib.qp_collision_onepass_available(ne))):
             if ks0 is not None:
