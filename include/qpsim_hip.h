@@ -184,6 +184,27 @@ int qp_collision_step_guarded(const qp_collision_tables* t, const uint8_t* flags
                               int enable_recombination, int enable_scattering, int update_phonons, double density_floor,
                               void* guard_workspace, double* out_vals, int64_t* out_idx, void* stream);
 
+/*
+ * TWO consecutive collision half-steps in one pass over the state: under Strang splitting the closing half-step of step k
+ * and the opening half-step of step k + 1 (solver.py:1469-1475) act on the same state with nothing between them but the
+ * Pauli guard of step k (solver.py:1477) and the explicit generation term of step k + 1 (solver.py:1459-1464) - unless step
+ * k is a store point.  Equivalent, bit for bit, to
+ *     qp_collision_step_guarded(state_in -> tmp, dt_first);   tmp += gen_amount on interior cells;
+ *     qp_collision_step(tmp -> state_out, dt_second)
+ * but n and the phonon planes make one round trip through HBM instead of two (the intermediate state never leaves the
+ * registers).  out_vals / out_idx: guard statistics of the INTERMEDIATE state (before the generation term), as
+ * qp_pauli_stats.  gen_amount: dt_{k+1} * rate for constant / active pulse generation, 0 otherwise.
+ * Returns QP_ERR_UNSUPPORTED (nothing launched, nothing written) when no fused kernel fits - qp_collision_pair_available(ne)
+ * is 0, more than one gap class, merged phonon bins (QP_COLL_SHARED_BINS), no diag_bin / anti_bin, a FORCE flag, no enabled
+ * process: the caller then issues the two calls above.  guard_workspace: qp_collision_guard_workspace_bytes(ncell).
+ */
+int qp_collision_pair_available(int32_t ne);
+int qp_collision_double_step_guarded(const qp_collision_tables* t, const uint8_t* flags, int64_t ncell, const double* state_in,
+                                     double* state_out, double* phonon, double dE, double dt_first, double dt_second,
+                                     double gen_amount, int enable_recombination, int enable_scattering, int update_phonons,
+                                     double density_floor, void* guard_workspace, double* out_vals, int64_t* out_idx,
+                                     void* stream);
+
 /* 1 when qp_collision_step has a register-resident kernel for `ne` energy bins (structured, unshared bin maps and one gap
  * class are the other conditions); other sizes <= 64 run the one-wave-per-pixel kernel, larger ones the generic kernel. */
 int qp_collision_register_kernel_available(int32_t ne);

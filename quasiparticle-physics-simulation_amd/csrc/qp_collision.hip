@@ -138,6 +138,10 @@ bool collision_onepass_dispatch(const qp_collision_tables& tb, double* stash, co
                                 hipStream_t stream);
 
 int collision_onepass_supported(int ne);
+int collision_pair_supported(int ne);
+bool collision_pair_dispatch(const qp_collision_tables& tb, const uint8_t* flags, long ncell, const double* sin_, double* sout,
+                             double* ph, double dE, double dt_a, double dt_b, double gen, bool s, bool r, bool u,
+                             PauliPartial* guard, double guard_floor, hipStream_t stream);
 int collision_fast_supported(int ne);
 int collision_fast_classes_supported(int ne);
 bool collision_fast_dispatch_classes(int ne, const double* rho, const int* cls, const double* gap_sq, const double* kr_amp,
@@ -321,6 +325,36 @@ extern "C" int qp_euler_collision(int32_t ne, int64_t ncell, const double* state
 
 // 1 when the register-resident collision kernel is instantiated for this number of energy bins
 extern "C" int qp_collision_register_kernel_available(int32_t ne) { return qp::collision_fast_supported(ne); }
+
+extern "C" int qp_collision_pair_available(int32_t ne) { return qp::collision_pair_supported(ne); }
+
+extern "C" int qp_collision_double_step_guarded(const qp_collision_tables* t, const uint8_t* flags, int64_t ncell,
+                                                const double* state_in, double* state_out, double* phonon, double dE,
+                                                double dt_first, double dt_second, double gen_amount,
+                                                int enable_recombination, int enable_scattering, int update_phonons,
+                                                double density_floor, void* guard_workspace, double* out_vals,
+                                                int64_t* out_idx, void* stream) {
+  QP_REQUIRE(t != nullptr, "tables are NULL");
+  if (t->struct_size != sizeof(qp_collision_tables)) {
+    qp::set_error("qp_collision_double_step_guarded: qp_collision_tables.struct_size is %u, this library expects %zu",
+                  t->struct_size, sizeof(qp_collision_tables));
+    return QP_ERR_INVALID_ARGUMENT;
+  }
+  QP_REQUIRE(flags && state_in && state_out && phonon && state_in != state_out, "flags, state_in, state_out (distinct), phonon");
+  QP_REQUIRE(guard_workspace && out_vals && out_idx, "guard_workspace, out_vals, out_idx must be non-NULL");
+  QP_REQUIRE(ncell > 0 && t->rho != nullptr, "ncell must be positive, rho non-NULL");
+  const bool s = enable_scattering && t->ks0, r = enable_recombination && t->kr0;
+  auto* parts = (qp::PauliPartial*)guard_workspace;
+  if (!qp::collision_pair_dispatch(*t, flags, (long)ncell, state_in, state_out, phonon, dE, dt_first, dt_second, gen_amount, s, r,
+                                   update_phonons && (s || r), parts + qp::kGuardMergeBlocks, density_floor,
+                                   (hipStream_t)stream)) {
+    qp::set_error("qp_collision_double_step_guarded: no fused double half-step kernel for these tables (ne = %d)", t->ne);
+    return QP_ERR_UNSUPPORTED;
+  }
+  const long nparts = ((long)ncell + 127) / 128 * 2;
+  qp::pauli_finish(parts + qp::kGuardMergeBlocks, nparts, parts, out_vals, (long*)out_idx, (hipStream_t)stream);
+  return qp::check_launch("qp_collision_double_step_guarded");
+}
 
 extern "C" int qp_collision_onepass_available(int32_t ne) { return qp::collision_onepass_supported(ne); }
 

@@ -105,6 +105,10 @@ SIGNATURES = {
     "qp_collision_register_kernel_available": (C.c_int, [C.c_int32]),
     "qp_collision_register_kernel_classes": (C.c_int, [C.c_int32]),
     "qp_collision_onepass_available": (C.c_int, [C.c_int32]),
+    "qp_collision_pair_available": (C.c_int, [C.c_int32]),
+    "qp_collision_double_step_guarded": (C.c_int, [C.POINTER(CollisionTables), c_dp, C.c_int64, c_dp, c_dp, c_dp, C.c_double,
+                                                   C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double,
+                                                   c_dp, c_dp, c_dp, c_dp]),
     "qp_adi_tile_plan_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.POINTER(C.c_double), c_dp, c_dp,
                                           c_dp, c_dp, c_dp, C.POINTER(C.POINTER(TilePlan))]),
     "qp_adi_tile_plan_create_var": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_double, c_dp, c_dp, c_dp, c_dp, c_dp,

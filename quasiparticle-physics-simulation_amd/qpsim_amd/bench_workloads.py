@@ -274,14 +274,32 @@ class CoupledWorkload:
             raise ValueError("Pauli guard tripped in the benchmark state")
         self.max_occ = max(self.max_occ, mx)
 
+    def _collide_pair(self, dt_a, dt_b):
+        """Closing half-step of one step + guard + opening half-step of the next as one pass (what `run_2d_crank_nicolson`
+        issues between store points when the tables allow it)."""
+        ticket = self.eng.collide_pair_guarded(self.tab, self.state, self.alt, self.phonon, self.dE, dt_a, dt_b, 0.0,
+                                               self.en_r, self.en_s, self.upd, 1e-18, ncell=self.npix, flags=self.coll_flags)
+        self.state, self.alt = self.alt, self.state
+        return ticket
+
     def run(self, k: int):
-        """k steps; the guard of step s is read on the host after step s + GUARD_LAG has been enqueued (every step is
-        checked, the last ones before returning) - as `run_2d_crank_nicolson` does."""
+        """k steps C(dt/2) D(dt) C(dt/2) + guard; the guard of step s is read on the host after step s + GUARD_LAG has been
+        enqueued (every step is checked, the last ones before returning) - as `run_2d_crank_nicolson` does.  Between two
+        steps the closing and the opening half-step run as one pass over the state where the tables allow it
+        (`tab["pair"]`: NE = 8, 12, one gap class, no merged bins) - the same 2 k half-steps, 2 k + 1 ... k + 1 launches."""
         pending = []
-        for _ in range(k):
-            self._collide(0.5 * self.dt)
+        pair = bool(self.tab.get("pair"))
+        opened = False
+        for s in range(k):
+            if not opened:
+                self._collide(0.5 * self.dt)
             self.eng.adi_steps(self.op, self.state, 1)
-            pending.append(self._collide(0.5 * self.dt, guarded=True))
+            if pair and s + 1 < k:
+                pending.append(self._collide_pair(0.5 * self.dt, 0.5 * self.dt))
+                opened = True
+            else:
+                pending.append(self._collide(0.5 * self.dt, guarded=True))
+                opened = False
             while len(pending) > self.eng.GUARD_LAG:
                 self._guard_check(pending.pop(0))
         for ticket in pending:

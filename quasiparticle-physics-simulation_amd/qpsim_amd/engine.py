@@ -897,6 +897,10 @@ class Engine:
                 h["ks0_diag"] = up(diagonal_major(np.asarray(ks0).reshape(ne, ne)), np.float64)
             if kr0 is not None:
                 h["kr0_anti2"] = up(antidiagonal_major(np.asarray(kr0).reshape(ne, ne), 2.0), np.float64)
+        # consecutive half-steps of neighbouring Strang steps in one pass (qp_collision_double_step_guarded)
+        h["pair"] = bool(h["kernel"] == "register" and nclass == 1 and structure is not None and not shared and symmetric
+                         and kernel == "auto" and self.lib.qp_collision_pair_available(ne)
+                         and os.environ.get("QPSIM_COLL_PAIR", "1") != "0")
         h["struct"] = _hip.CollisionTables.make(ne, nw, nclass, _ptr(h["kr0"]), _ptr(h["ks0"]), _ptr(h["rho"]),
                                            _ptr(h["idx_diff"]), _ptr(h["idx_sum"]), _ptr(h["sign"]), _ptr(h["cls"]),
                                            _ptr(h["diag_bin"]), _ptr(h["anti_bin"]), flag_bits,
@@ -934,6 +938,28 @@ class Engine:
             C.byref(tables["struct"]), _ptr(self.d_flags if flags is None else flags), nc, _ptr(state), _ptr(state_out),
             _ptr(phonon), _ptr(acc), float(dE), float(dt), int(bool(en_r)), int(bool(en_s)), int(bool(update_phonons)),
             float(floor), _ptr(ws), _ptr(self._red_vals), _ptr(self._red_idx), self.stream), "qp_collision_step_guarded")
+        hv.copy_(self._red_vals, non_blocking=True)
+        hi.copy_(self._red_idx, non_blocking=True)
+        ev.record(self.torch.cuda.current_stream(self.device))
+        return hv, hi, ev, nc
+
+    def collide_pair_guarded(self, tables, state, state_out, phonon, dE, dt_first, dt_second, gen_amount, en_r, en_s,
+                             update_phonons, floor: float, ncell: int | None = None, flags=None):
+        """The closing collision half-step of one Strang step, its Pauli guard, the constant / pulse generation term of the
+        next step and that step's opening half-step as ONE pass over the state (``qp_collision_double_step_guarded``; only
+        call when ``tables["pair"]``).  Returns the guard ticket of the step that closes (as ``collide_guarded``)."""
+        nc = self.ncell if ncell is None else int(ncell)
+        nbytes = int(self.lib.qp_collision_guard_workspace_bytes(nc))
+        ws = getattr(self, "_guard_ws", None)
+        if ws is None or ws.numel() < nbytes:
+            ws = self._guard_ws = self.torch.empty(nbytes, dtype=self.torch.uint8, device=self.device)
+        hv, hi, ev = self._guard_slot()
+        self._guard_ne = tables["ne"]
+        _hip.check(self.lib.qp_collision_double_step_guarded(
+            C.byref(tables["struct"]), _ptr(self.d_flags if flags is None else flags), nc, _ptr(state), _ptr(state_out),
+            _ptr(phonon), float(dE), float(dt_first), float(dt_second), float(gen_amount), int(bool(en_r)), int(bool(en_s)),
+            int(bool(update_phonons)), float(floor), _ptr(ws), _ptr(self._red_vals), _ptr(self._red_idx), self.stream),
+            "qp_collision_double_step_guarded")
         hv.copy_(self._red_vals, non_blocking=True)
         hi.copy_(self._red_idx, non_blocking=True)
         ev.record(self.torch.cuda.current_stream(self.device))

@@ -608,9 +608,27 @@ def run_2d_crank_nicolson(
     batch_diffusion = (enable_diffusion and not collisions and not gen_active and diffusion_scheme == "adi"
                        and pauli_error_threshold is None and pauli_warn_threshold is None
                        and float(np.min(rho_tab)) > 1e-30)
+    def generation_amount(t_start: float, dt_of_step: float):
+        """dt g_ext of a step that starts at ``t_start`` when it is one number for all bins and pixels (constant / pulse
+        modes), None when it is not (custom mode); 0.0 without generation."""
+        if not gen_active:
+            return 0.0
+        if gen_mode == "constant":
+            return dt_of_step * float(external_generation.rate)
+        if gen_mode == "pulse":
+            on = external_generation.pulse_start <= t_start < (external_generation.pulse_start
+                                                               + external_generation.pulse_duration)
+            return dt_of_step * float(external_generation.pulse_rate) if on else 0.0
+        return None if gen_mode == "custom" else 0.0
+
     current_time = 0.0
     done = 0
     custom_generation = None                                     # compiled at its first use, then reused every step
+    # Strang steps that follow one another without a store point in between: the closing half-step of step k and the
+    # opening half-step of step k + 1 run as ONE pass over the state (Engine.collide_pair_guarded) - `opened` says that
+    # the generation term and the first half-step of the step now starting were already applied by that pass.
+    pair_ok = bool(collisions and enable_diffusion and ctab.get("pair"))
+    opened = False
     for step in range(1, total_steps + 1):                       # solver.py:1454-1494
         final = step > full_steps
         dt_step = rem if final else dt
@@ -622,27 +640,36 @@ def run_2d_crank_nicolson(
                 times.append(float(current_time))
                 _notify(progress_callback, current_time, store())
             continue
-        if gen_active:
-            if gen_mode == "constant":
-                external_generation_rate = float(external_generation.rate)
-                eng.add_constant(state, dt_step * external_generation_rate)
-            elif gen_mode == "pulse":
-                on = external_generation.pulse_start <= current_time < (external_generation.pulse_start
-                                                                        + external_generation.pulse_duration)
-                if on:
-                    eng.add_constant(state, dt_step * float(external_generation.pulse_rate))
-            elif gen_mode == "custom":
+        if gen_active and not opened:
+            amount = generation_amount(current_time, dt_step)
+            if amount is None:                                   # custom mode: evaluated on the host (solver.py:918-962)
                 if custom_generation is None:
                     custom_generation = _CustomGeneration(external_generation, mask)
                 g_ext = evaluate_external_generation(external_generation, E_bins, n, current_time, mask,
                                                      _compiled=custom_generation)
                 if g_ext is not None:
                     eng.add_scaled(state, eng.upload_packed(g_ext), dt_step)
+            elif gen_mode == "constant" or amount != 0.0:
+                eng.add_constant(state, amount)
         guarded = False
         if collisions and enable_diffusion:                      # Strang: C(dt/2) D(dt) C(dt/2)
-            collide(0.5 * dt_step)
+            if not opened:
+                collide(0.5 * dt_step)
+            opened = False
             diffuser.step(state, final)
-            guarded = collide(0.5 * dt_step, guard_step=(step, current_time + dt_step))
+            nxt_amount = None
+            if pair_ok and step < total_steps and not stored(step) and dt_step > 0.0:
+                dt_next = rem if step + 1 > full_steps else dt
+                nxt_amount = generation_amount(current_time + dt_step, dt_next)
+            if nxt_amount is not None:
+                ticket = eng.collide_pair_guarded(ctab, state, state_alt, phonon, dE, 0.5 * dt_step, 0.5 * dt_next,
+                                                  nxt_amount, enable_recombination, enable_scattering,
+                                                  not freeze_phonon_dynamics, pauli_density_floor)
+                pending_guard.append((ticket, step, current_time + dt_step))
+                state, state_alt = state_alt, state
+                guarded = opened = True
+            else:
+                guarded = collide(0.5 * dt_step, guard_step=(step, current_time + dt_step))
         else:
             diffuse_after = enable_diffusion and dt_step > 0.0
             guarded = collide(dt_step, guard_step=None if diffuse_after else (step, current_time + dt_step))

@@ -478,3 +478,79 @@ def test_one_pass_ne50_kernel_equals_the_split_kernels_on_a_ragged_masked_grid(m
     assert np.all(outs["1"][2][:, hole] == 0.0) and np.all(outs["1"][3][:, hole] == 0.0)
     if not upd:
         assert np.array_equal(outs["1"][1], ph)
+
+
+@pytest.mark.parametrize("ne,combo", [(12, (True, True, True)), (12, (True, False, False)), (12, (False, True, True)),
+                                      (8, (True, True, True)), (8, (True, True, False)), (16, (True, True, True)), (5, (False, True, True))])
+def test_double_half_step_kernel_equals_two_calls_bit_for_bit(ne, combo):
+    """qp_collision_double_step_guarded = guarded half-step + generation term + half-step with the intermediate state kept
+    in registers: quasiparticle planes, phonon planes and the guard statistics of the INTERMEDIATE state must equal the
+    two-call sequence exactly (same arithmetic, operation for operation), on a masked grid with a ragged last block."""
+    from qpsim_amd import tables as T
+    from qpsim_amd.engine import CompiledGeometry, Engine, link_flags
+    en_r, en_s, upd = combo
+    rng = np.random.default_rng(ne + 5)
+    mask = rng.random((19, 41)) > 0.2
+    z = np.zeros(mask.shape)
+    eng = Engine(CompiledGeometry(mask, 1.0, link_flags(mask), z, z, z, z))
+    n = int(mask.sum())
+    E, dE = T.build_energy_grid(180.0, 1.0, 3.0, ne)
+    om, idx_d, idx_s, sg = T.build_phonon_frequency_map(E)
+    rho = T.dynes_density_of_states(E, 180.0, 0.1)
+    kr, ks = T.recombination_kernel_base(E, 180.0, 500.0, 1.2), T.scattering_kernel_base(E, 180.0, 400.0, 1.2)
+    state = rng.random((ne, n)) * rho[:, None] * rng.choice([1e-5, 1e-2, 0.5, 0.9], size=n)[None, :]
+    ph = T.thermal_phonon_occupation(om, 0.3)[:, None] * (0.5 + rng.random((om.size, n)))
+    tab = eng.make_collision_tables(kr[None], ks[None], rho[None], idx_d, idx_s, sg)
+    assert tab["kernel"] == "register" and tab["pair"]
+    dt_a, dt_b, gen = 0.05, 0.03, 2.5e-7
+    # two calls
+    s0, p_two = eng.upload_packed(state), eng.upload_packed(ph)
+    s1, s2 = eng.empty(ne, eng.ncell), eng.empty(ne, eng.ncell)
+    stats_two = eng.pauli_stats_result(eng.collide_guarded(tab, s0, s1, p_two, dE, dt_a, en_r, en_s, upd, 1e-18))
+    eng.add_constant(s1, gen)
+    eng.collide(tab, s1, s2, p_two, dE, dt_b, en_r, en_s, upd)
+    # one pass
+    t0, p_one = eng.upload_packed(state), eng.upload_packed(ph)
+    t2 = eng.empty(ne, eng.ncell)
+    t2.fill_(-3.0)
+    stats_one = eng.pauli_stats_result(eng.collide_pair_guarded(tab, t0, t2, p_one, dE, dt_a, dt_b, gen, en_r, en_s, upd, 1e-18))
+    assert stats_one == stats_two
+    assert np.array_equal(t2.cpu().numpy(), s2.cpu().numpy())
+    assert np.array_equal(p_one.cpu().numpy(), p_two.cpu().numpy())
+    if not upd:
+        assert np.array_equal(eng.download_packed(p_one), ph)
+
+
+@pytest.mark.parametrize("gen", ["none", "constant", "pulse"])
+def test_run_with_fused_half_steps_equals_the_run_without(monkeypatch, gen):
+    """`run_2d_crank_nicolson`, NE = 12 full physics, stores every 3rd step, a short remainder step, generation that
+    switches on and off inside the run: with the double half-step passes between store points (default) and with every
+    half-step as its own call (QPSIM_COLL_PAIR=0) the outputs are identical - frames, energy frames, masses, phonon
+    history, and the warning the guard raises."""
+    import warnings
+    from qpsim_amd.models import ExternalGenerationSpec
+    from qpsim_amd.solver import run_2d_crank_nicolson
+    mask, edges, bcs = _rect_problem(20, 28)
+    init = 1e-3 * (1.0 + np.random.default_rng(2).random(mask.shape))
+    spec = {"none": None, "constant": ExternalGenerationSpec(mode="constant", rate=3e-6),
+            "pulse": ExternalGenerationSpec(mode="pulse", pulse_start=0.25, pulse_duration=0.3, pulse_rate=4e-5)}[gen]
+    kw = dict(mask=mask, edges=edges, edge_conditions=bcs, initial_field=init, diffusion_coefficient=6.0, dt=0.1,
+              total_time=1.05, dx=1.0, store_every=3, energy_gap=180.0, energy_min_factor=1.0, energy_max_factor=3.0,
+              num_energy_bins=12, enable_diffusion=True, enable_recombination=True, enable_scattering=True,
+              external_generation=spec, diffusion_scheme="adi", pauli_warn_threshold=None)
+    outs = {}
+    for pair in ("1", "0"):
+        monkeypatch.setenv("QPSIM_COLL_PAIR", pair)
+        hist = {}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res = run_2d_crank_nicolson(**kw, phonon_history_out=hist)
+        outs[pair] = (res, hist)
+    a, b = outs["1"], outs["0"]
+    assert a[0][0] == b[0][0] and a[0][2] == b[0][2] and len(a[0][0]) == 5     # t = 0, 0.3, 0.6, 0.9, 1.05
+    for fa, fb in zip(a[0][1], b[0][1]):
+        assert np.array_equal(fa, fb, equal_nan=True)
+    for ea, eb in zip(a[0][4], b[0][4]):
+        assert np.array_equal(np.stack(ea), np.stack(eb), equal_nan=True)
+    for pa, pb in zip(a[1]["phonon_energy_frames"], b[1]["phonon_energy_frames"]):
+        assert np.array_equal(np.stack(pa), np.stack(pb), equal_nan=True)
