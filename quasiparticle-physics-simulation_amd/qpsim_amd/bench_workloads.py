@@ -85,10 +85,12 @@ class ADIWorkload:
         prof = Path(__file__).resolve().parents[2] / "profiles"
         if self.nfield != 1 or self.N not in ((4096,) if self.ring else (1024, 2048, 4096)):
             return None
-        name = "r02_ring4096_pmc.json" if self.ring else f"r02_adi{self.N}_pmc.json"
-        if not (prof / name).exists():
+        stem = "ring4096_pmc.json" if self.ring else f"adi{self.N}_pmc.json"
+        found = sorted(prof.glob(f"r0*_{stem}"))          # the latest round's passes
+        if not found:
             return None
-        k = json.loads((prof / name).read_text())["kernels"]
+        self._traffic_file = found[-1].name
+        k = json.loads(found[-1].read_text())["kernels"]
         pick = lambda frag: sum(v["hbm_bytes_per_launch"] for n_, v in k.items() if frag in n_)  # noqa: E731
         if self.op.rect is not None and self.op.rect.fine:
             val = 0.5 * (pick("fine_x_kernel<true, 0, false>") + pick("fine_y_kernel<1, 0, false>"))
@@ -122,8 +124,8 @@ class ADIWorkload:
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": None if traffic is None else
-                "profiles/r02_*_pmc.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not measured "
-                "in this run)",
+                f"profiles/{getattr(self, '_traffic_file', '')} (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                "workload, not measured in this run)",
                 "kernel": ("fine_x_kernel / fine_y_kernel (one tile sweep, 32-cell chunks)"
                            if self.op.rect is not None and self.op.rect.fine else
                            "rect_x_kernel / rect_y_kernel (one tile sweep)" if self.op.rect is not None else
@@ -305,50 +307,64 @@ class CoupledWorkload:
         for ticket in pending:
             self._guard_check(ticket)
 
-    def _pmc_traffic(self):
-        """HBM bytes per collision call from the committed PMC summary of `--workload c3` (profiles/r01_c3_pmc.json)."""
+    def _pmc_traffic(self, pair: bool):
+        """HBM bytes per launch of the dominant collision kernel from the committed PMC summary of `--workload c3`
+        (profiles/r03_c3_pmc.json; separate rocprofv3 --pmc passes of this same command)."""
         import json
         from pathlib import Path
-        f = Path(__file__).resolve().parents[2] / "profiles" / "r02_c3_pmc.json"
+        f = Path(__file__).resolve().parents[2] / "profiles" / "r03_c3_pmc.json"
         if not (self.N == 4096 and self.ne == 12 and self.members == 1 and self.upd and self.en_s and f.exists()):
             return None
+        want = "collision_pair_kernel<12, true, true, true>" if pair else "collision_diag_kernel<12, true, true, true, false>"
         for name, v in json.loads(f.read_text())["kernels"].items():
-            if "collision_diag_kernel<12, true, true, true, false>" in name:
+            if want in name:
                 return v["hbm_bytes_per_launch"]
         return None
 
     def roofline(self, nrep: int) -> dict:
-        """Dominant kernel = the collision update (two calls per step): HIP-event time per call vs its plane traffic."""
+        """Dominant kernel = the collision update: HIP-event time per launch vs the ALGORITHMIC bytes of the pixel-updates
+        that launch performs (16 (NE + Nw) B per pixel-update).  Where the time loop runs the double half-step
+        pass (`tab["pair"]`) one launch performs TWO pixel-updates per pixel, so its algorithmic bytes are twice a
+        call's - while the bytes it actually moves are those of one (the intermediate state stays in registers): the
+        `traffic` counter then reads about half of `bytes_per_launch`."""
+        import os
         torch = self.eng.torch
         dev = self.eng.device
-        self._collide(0.5 * self.dt)
+        pair = bool(self.tab.get("pair"))
+        step = (lambda: self._collide_pair(0.5 * self.dt, 0.5 * self.dt)) if pair else (lambda: self._collide(0.5 * self.dt))
+        updates = 2 if pair else 1
+        step()
         torch.cuda.synchronize(dev)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record(torch.cuda.current_stream(dev))
         for _ in range(nrep):
-            self._collide(0.5 * self.dt)
+            step()
         ev1.record(torch.cuda.current_stream(dev))
         torch.cuda.synchronize(dev)
         per_call = ev0.elapsed_time(ev1) * 1e-3 / nrep
-        achieved = self.coll_bytes_per_call / per_call / 1e9
+        nbytes = updates * self.coll_bytes_per_call
+        achieved = nbytes / per_call / 1e9
         pairs = self.ne * self.ne
-        flops = 26.0 * pairs * self.npix               # SURVEY 8(d): ~26 NE^2 flop per pixel-update
+        flops = updates * 26.0 * pairs * self.npix     # SURVEY 8(d): ~26 NE^2 flop per pixel-update
         tflops = flops / per_call / 1e12
-        import os
         onepass = (self.tab.get("ks0_diag") is not None or self.tab.get("kr0_anti2") is not None) \
             and os.environ.get("QPSIM_COLL_ONEPASS", "1") != "0"
-        kernel = {"register": "collision_diag_kernel" if self.ne < 32 else
-                  "collision_onepass_kernel (one launch, tables staged in LDS)" if onepass else
-                  "collision_range_kernel x2 + collision_phonon_kernel (one call)", "wave": "collision_wave_kernel",
-                  "generic": "collision_generic_kernel"}[self.tab["kernel"]]
-        traffic, source = self._pmc_traffic(), None
+        kernel = {"register": ("collision_pair_kernel (two half-steps per launch, intermediate state in registers)" if pair else
+                               "collision_diag_kernel" if self.ne < 32 else
+                               "collision_onepass_kernel (one launch, tables staged in LDS)" if onepass else
+                               "collision_range_kernel x2 + collision_phonon_kernel (one call)"),
+                  "wave": "collision_wave_kernel", "generic": "collision_generic_kernel"}[self.tab["kernel"]]
+        traffic, source = self._pmc_traffic(pair), None
         if traffic is not None:
-            source = "profiles/r02_c3_pmc.json (committed rocprofv3 --pmc passes of this workload, not measured in this run)"
-        common = {"traffic": traffic, "traffic_source": source, "kernel": kernel, "bytes_per_launch": self.coll_bytes_per_call,
-                  "flops_per_launch": flops, "avg_launch_us": per_call * 1e6, "pixel_updates_per_s": self.npix / per_call,
+            source = "profiles/r03_c3_pmc.json (committed rocprofv3 --pmc passes of this workload, not measured in this run)"
+        common = {"traffic": traffic, "traffic_source": source, "kernel": kernel, "bytes_per_launch": nbytes,
+                  "pixel_updates_per_launch": updates * self.npix,
+                  "flops_per_launch": flops, "avg_launch_us": per_call * 1e6,
+                  "pixel_updates_per_s": updates * self.npix / per_call,
                   "hbm_gbs": achieved, "hbm_frac": achieved / HBM_PEAK_GBS, "fp64_tflops": tflops,
                   "fp64_frac": tflops / FP64_VECTOR_PEAK_TFLOPS,
-                  "note": f"16*(NE+Nw) B per pixel when phonons are dynamic; ~26*NE^2 = {26 * pairs} flop per pixel-update"}
+                  "note": (f"algorithmic bytes: 16*(NE+Nw) B per pixel-update when phonons are dynamic, x {updates} "
+                           f"pixel-update(s) per pixel and launch; ~26*NE^2 = {26 * pairs} flop per pixel-update")}
         if self.ne >= 20:      # 26 NE^2 flop against 16 (NE + Nw) B per pixel: above NE ~ 20 the fp64 vector rate bounds it
             return {"bound": "fp64", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, **common}

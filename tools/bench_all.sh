@@ -2,7 +2,7 @@
 # Runs the benchmark workloads of DESIGN.md section 6 on one GPU; one JSON line per workload under $1.
 out=$1; mkdir -p $out
 python bench.py > $out/bench_adi4096.json 2> $out/bench_adi4096.err
-for w in adi8192 adi2048 adi1024 adi256x768 cn4096 cn1024 c2 c3 c4 ring4096 ring4096x12 coupled1024ne50 dd8192 dd8192c ddx8192; do
+for w in adi8192 adi2048 adi1024 adi256x768 cn4096 cn1024 c2 c3 c4 ring4096 ring4096x12 coupled1024ne32 coupled1024ne40 coupled1024ne50 coupled1024ne50gap4 dd8192 dd8192c ddx8192; do
   python bench.py --workload $w --steps 30 --warmup 5 --no-cpu-baseline > $out/bench_$w.json 2> $out/bench_$w.err
 done
 python bench.py --force-dist --force-subrecords --steps 30 --warmup 5 --no-cpu-baseline > $out/bench_subrecords_1rank.json 2> $out/bench_subrecords_1rank.err

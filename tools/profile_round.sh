@@ -8,13 +8,13 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p $R/$out; cd /tmp; export TMPDIR=/tmp
 stats() {   # name, bench args
   want $1 || return 0
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/$1_stats -o s -- python3 $R/bench.py $2 --no-cpu-baseline > $R/$out/$1_bench_under_rocprof.json 2> $R/$out/$1_stats.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/$1_stats -o s -- python3 $R/bench.py $2 --no-cpu-baseline --sustained-seconds 0 > $R/$out/$1_bench_under_rocprof.json 2> $R/$out/$1_stats.err
   cp $(find $R/$out/$1_stats -name "*kernel_stats.csv" | head -1) $R/$out/$1_kernel_stats.csv
 }
 traffic() { # name, bench args
   want $1 || return 0
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$out/$1_fetch -o f -- python3 $R/bench.py $2 --no-cpu-baseline > /dev/null 2> $R/$out/$1_fetch.err
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$out/$1_write -o w -- python3 $R/bench.py $2 --no-cpu-baseline > /dev/null 2> $R/$out/$1_write.err
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$out/$1_fetch -o f -- python3 $R/bench.py $2 --no-cpu-baseline --sustained-seconds 0 > /dev/null 2> $R/$out/$1_fetch.err
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$out/$1_write -o w -- python3 $R/bench.py $2 --no-cpu-baseline --sustained-seconds 0 > /dev/null 2> $R/$out/$1_write.err
   (cd $R && python tools/pmc_summary.py $(find $out/$1_fetch -name "*counter_collection.csv") $(find $out/$1_write -name "*counter_collection.csv") $out/$1_pmc.json > $out/$1_pmc.txt 2>&1)
 }
 stats adi4096 "--steps 50 --warmup 10"
@@ -30,4 +30,7 @@ stats adi1024 "--workload adi1024 --steps 400 --warmup 40"
 traffic adi1024 "--workload adi1024 --steps 100 --warmup 10"
 traffic adi2048 "--workload adi2048 --steps 50 --warmup 5"
 stats coupled1024ne50 "--workload coupled1024ne50 --steps 6 --warmup 2"
+traffic coupled1024ne50 "--workload coupled1024ne50 --steps 4 --warmup 1"
+stats c4 "--workload c4 --steps 20 --warmup 3"
+stats cn4096 "--workload cn4096 --steps 20 --warmup 3"
 cd $R && cat $out/*_pmc.txt | cut -c1-170
