@@ -267,3 +267,26 @@ def test_four_processes_2x2_coupled_step_over_gloo(tmp_path):
         j0, i0, ny, nx = BlockTopology(N, N, 2, 2, r).block
         got = np.load(tmp_path / f"own_{r}.npy")
         assert np.max(np.abs(got - ref[:, j0:j0 + ny, i0:i0 + nx])) / np.max(np.abs(ref)) < 1e-13, r
+
+
+def test_halo_entry_points_refuse_plans_without_interface_rows():
+    """`qp_adi_rect_iface_halo` / `qp_adi_rect_set_field_halo` copy nfield x nlines doubles into / out of arrays
+    that only block plans of a decomposed grid own (a Peaceman-Rachford plan on fine tiles allocates one element): any other
+    plan must be refused, not read out of bounds."""
+    import ctypes as C
+    import torch
+    from qpsim_amd import _hip
+    from qpsim_amd.engine import RectPlan
+    lib = _hip.load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    buf = torch.zeros(2 * 128, dtype=torch.float64, device=dev)
+    stream = int(torch.cuda.current_stream(dev).cuda_stream)
+    whole = RectPlan(lib, 128, 128, 2, 0.05, [6.0, 1.0], [0.0] * 4, [0.0] * 4)
+    pr = RectPlan.peaceman_rachford(lib, 128, 128, 2, 0.05, [6.0, 1.0], [0.0] * 4, 1.0)
+    for plan in (whole, pr):
+        assert lib.qp_adi_rect_iface_halo(plan.handle, 0, 0, 0, int(buf.data_ptr()), stream) == -1
+        assert b"decomposed grid" in lib.qp_last_error()
+        assert lib.qp_adi_rect_set_field_halo(plan.handle, 0, int(buf.data_ptr()), stream) == -1
+    block = RectPlan(lib, 128, 128, 2, 0.05, [6.0, 1.0], [0.0] * 4, [0.0] * 4, block=(128, 256, 0, 0))
+    assert lib.qp_adi_rect_iface_halo(block.handle, 0, 1, 0, int(buf.data_ptr()), stream) == 0
+    torch.cuda.synchronize()
