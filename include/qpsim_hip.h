@@ -208,7 +208,7 @@ int qp_collision_double_step_guarded(const qp_collision_tables* t, const uint8_t
 /* 1 when qp_collision_step has a register-resident kernel for `ne` energy bins (structured, unshared bin maps and one gap
  * class are the other conditions); other sizes <= 64 run the one-wave-per-pixel kernel, larger ones the generic kernel. */
 int qp_collision_register_kernel_available(int32_t ne);
-/* 1 when the one-pass kernel (ks0_diag / kr0_anti2 above) is instantiated for `ne` energy bins: ne = 32, 40 and 50 (the
+/* 1 when the one-pass kernel (ks0_diag / kr0_anti2 above) is instantiated for `ne` energy bins: ne = 30, 32, 40 and 50 (the
  * reference's default num_energy_bins, solver.py:1012). */
 int qp_collision_onepass_available(int32_t ne);
 /* 1 when the register-resident kernel also has its gap-class variant for `ne` (single-pass sizes: ne <= 16, 18, 20, 24, 30). */
@@ -312,7 +312,8 @@ int qp_adi_rect_steps(qp_adi_rect_plan* plan, double* u, int32_t nsteps, void* s
 /* qp_stencil_combine for the plan's operator without per-cell geometry arrays (positions decide which side term applies):
  * out = c0 u + cx (a Lx u) + cy (a Ly u) + cs a S + cr rin on [nfield][ny*nx]; with norm_out non-NULL also
  * norm_out[0] = max |out| (workspace: qp_pauli_workspace_bytes() bytes), which saves the exact-CN iteration its
- * separate norm pass.  (1,1,1,2,0) = CN right-hand side, (-1,1,1,0,1) = residual rin - (I - a L) u. */
+ * separate norm pass.  (1,1,1,2,0) = CN right-hand side, (-1,1,1,0,1) = residual rin - (I - a L) u.  `out` may be NULL when
+ * norm_out is given: only the norm is formed (the residual CHECK after a Peaceman-Rachford cycle: one plane less to move). */
 int qp_adi_rect_combine(qp_adi_rect_plan* plan, const double* u, const double* rin, double* out, double c0, double cx,
                         double cy, double cs, double cr, void* workspace, double* norm_out, void* stream);
 /* x[nfield][ny*nx] <- (I - a Ly)^-1 (I - a Lx)^-1 x in place: the ADI factorisation applied as the preconditioner of

@@ -547,6 +547,9 @@ struct RectSides {
 // the 5-point operator of qp_stencil_combine without its per-cell geometry arrays (33 B per cell) - positions decide.  With
 // `part` non-NULL every block also leaves max |out| of its cells there (the convergence check of the exact-CN iteration
 // then needs no pass of its own; NaN is propagated as +inf).
+// STORE = false: only the norm is wanted (the residual CHECK of the exact-CN step: its plane is read again only when the
+// check fails) - one plane transfer less.  RB: rows per band of the 4-cells-per-thread branch (two halo rows per band).
+template <bool STORE, int RB>
 __global__ void __launch_bounds__(256) rect_combine_kernel(int ny, int nx, int nfield, const double* __restrict__ alpha,
                                                            RectSides g, const double* __restrict__ u,
                                                            const double* __restrict__ rin, double* __restrict__ out,
@@ -566,7 +569,6 @@ __global__ void __launch_bounds__(256) rect_combine_kernel(int ny, int nx, int n
     // A block walks bands of RB rows of one field; a thread owns a strip 4 cells wide and walks down the band with the row
     // above, the row itself and the row below in registers: every row of u is loaded once per band (+2 halo rows per RB)
     // as two 16-byte loads per thread, the two cells beside the strip as 8-byte loads (cache hits) - no per-cell division.
-    constexpr int RB = 8;
     const int bands_per_field = (ny + RB - 1) / RB;
     const int chunk = 4 * blockDim.x, chunks = (nx + chunk - 1) / chunk;      // column chunks of one strip per thread
     for (long item = blockIdx.x; item < (long)nfield * bands_per_field * chunks; item += gridDim.x) {
@@ -600,8 +602,10 @@ __global__ void __launch_bounds__(256) rect_combine_kernel(int ny, int nx, int n
             const double2 q0 = *reinterpret_cast<const double2*>(rin + t0), q1 = *reinterpret_cast<const double2*>(rin + t0 + 2);
             res[0] += cr * q0.x; res[1] += cr * q0.y; res[2] += cr * q1.x; res[3] += cr * q1.y;
           }
-          *reinterpret_cast<double2*>(out + t0) = make_double2(res[0], res[1]);
-          *reinterpret_cast<double2*>(out + t0 + 2) = make_double2(res[2], res[3]);
+          if (STORE) {
+            *reinterpret_cast<double2*>(out + t0) = make_double2(res[0], res[1]);
+            *reinterpret_cast<double2*>(out + t0 + 2) = make_double2(res[2], res[3]);
+          }
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const double v = fabs(res[q]);
@@ -623,7 +627,7 @@ __global__ void __launch_bounds__(256) rect_combine_kernel(int ny, int nx, int n
         double res = cell(a, i, j, i > 0 ? ub[i - 1] : 0.0, ub[i], i < nx - 1 ? ub[i + 1] : 0.0, j > 0 ? ub[i - nx] : 0.0,
                           j < ny - 1 ? ub[i + nx] : 0.0);
         if (cr != 0.0) res += cr * rin[t0 + i];
-        out[t0 + i] = res;
+        if (STORE) out[t0 + i] = res;
         const double v = fabs(res);
         m = (v != v) ? __builtin_huge_val() : fmax(m, v);
       }
@@ -1140,7 +1144,8 @@ int qp_adi_rect_solve(qp_adi_rect_plan* plan, double* x, void* stream_) {
 // norm_out non-NULL also norm_out[0] = max |out| (workspace: qp_pauli_workspace_bytes() bytes).
 int qp_adi_rect_combine(qp_adi_rect_plan* plan, const double* u, const double* rin, double* out, double c0, double cx,
                         double cy, double cs, double cr, void* workspace, double* norm_out, void* stream_) {
-  QP_REQUIRE(plan && u && out, "plan, u, out must be non-NULL");
+  QP_REQUIRE(plan && u, "plan and u must be non-NULL");
+  QP_REQUIRE(out || norm_out, "out may be NULL only when the norm is wanted (norm_out)");
   QP_REQUIRE(cr == 0.0 || rin, "rin is required when cr != 0");
   QP_REQUIRE(!plan->decomposed, "qp_adi_rect_combine is not available on decomposed plans");
   QP_REQUIRE((norm_out == nullptr) || workspace, "workspace is required with norm_out");
@@ -1148,7 +1153,8 @@ int qp_adi_rect_combine(qp_adi_rect_plan* plan, const double* u, const double* r
   hipStream_t stream = (hipStream_t)stream_;
   const RectView& v = plan->view;
   // one band of 8 rows (row lengths that are multiples of 4) or one row per block and trip
-  long blocks = (v.d.nx & 3) == 0 ? (long)v.d.nfield * ((v.d.ny + 7) / 8) * ((v.d.nx + 1023) / 1024)
+  constexpr int RB = 16;
+  long blocks = (v.d.nx & 3) == 0 ? (long)v.d.nfield * ((v.d.ny + RB - 1) / RB) * ((v.d.nx + 1023) / 1024)
                                   : (long)v.d.nfield * v.d.ny;
   if (blocks > 1024) blocks = 1024;         // = the partial slots of the reduction workspace
   // only the 4-cells-per-thread branch makes 16-byte accesses (per-field views with odd ncell take the row branch)
@@ -1158,9 +1164,13 @@ int qp_adi_rect_combine(qp_adi_rect_plan* plan, const double* u, const double* r
               plan->bc_src[0], plan->bc_src[1], plan->bc_src[2], plan->bc_src[3]};
   if (v.d.nx == 1) { g.dr = 0.0; g.sr = 0.0; }   // one column: rect_side_terms folds both x-faces into the "left" slot
   if (v.d.ny == 1) { g.dd = 0.0; g.sd = 0.0; }
-  hipLaunchKernelGGL(rect_combine_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, v.d.ny, v.d.nx, v.d.nfield,
-                     (const double*)plan->d_alpha, g, u, rin, out, c0, cx, cy, cs, cr,
-                     norm_out ? (double*)workspace : nullptr);
+  if (out)
+    hipLaunchKernelGGL((rect_combine_kernel<true, RB>), dim3((unsigned)blocks), dim3(256), 0, stream, v.d.ny, v.d.nx, v.d.nfield,
+                       (const double*)plan->d_alpha, g, u, rin, out, c0, cx, cy, cs, cr,
+                       norm_out ? (double*)workspace : nullptr);
+  else
+    hipLaunchKernelGGL((rect_combine_kernel<false, RB>), dim3((unsigned)blocks), dim3(256), 0, stream, v.d.ny, v.d.nx, v.d.nfield,
+                       (const double*)plan->d_alpha, g, u, rin, out, c0, cx, cy, cs, cr, (double*)workspace);
   if (norm_out) absmax_finish((const double*)workspace, (int)blocks, norm_out, stream);
   return check_launch("qp_adi_rect_combine");
 }

@@ -9,6 +9,7 @@ namespace qp {
 QP_DECLARE_ONEPASS(50)
 QP_DECLARE_ONEPASS(40)
 QP_DECLARE_ONEPASS(32)
+QP_DECLARE_ONEPASS(30)
 
 static bool onepass_enabled() {      // QPSIM_COLL_ONEPASS=0: the three-launch split kernels (A/B timing, tests)
   const char* e = getenv("QPSIM_COLL_ONEPASS");
@@ -32,12 +33,13 @@ bool collision_onepass_dispatch(const qp_collision_tables& tb, double* stash, co
     case 50: fn = (s && r) ? onepass_50_11 : r ? onepass_50_01 : onepass_50_10; break;
     case 40: fn = (s && r) ? onepass_40_11 : r ? onepass_40_01 : onepass_40_10; break;
     case 32: fn = (s && r) ? onepass_32_11 : r ? onepass_32_01 : onepass_32_10; break;
+    case 30: fn = (s && r) ? onepass_30_11 : r ? onepass_30_01 : onepass_30_10; break;
     default: return false;
   }
   fn(v, flags, ncell, sin_, sout, ph, dE, dt, u, stream);
   return true;
 }
 
-int collision_onepass_supported(int ne) { return (ne == 50 || ne == 40 || ne == 32) ? 1 : 0; }
+int collision_onepass_supported(int ne) { return (ne == 50 || ne == 40 || ne == 32 || ne == 30) ? 1 : 0; }
 
 }  // namespace qp

@@ -350,8 +350,8 @@ class CoupledWorkload:
         onepass = (self.tab.get("ks0_diag") is not None or self.tab.get("kr0_anti2") is not None) \
             and os.environ.get("QPSIM_COLL_ONEPASS", "1") != "0"
         kernel = {"register": ("collision_pair_kernel (two half-steps per launch, intermediate state in registers)" if pair else
-                               "collision_diag_kernel" if self.ne < 32 else
                                "collision_onepass_kernel (one launch, tables staged in LDS)" if onepass else
+                               "collision_diag_kernel" if self.ne < 32 else
                                "collision_range_kernel x2 + collision_phonon_kernel (one call)"),
                   "wave": "collision_wave_kernel", "generic": "collision_generic_kernel"}[self.tab["kernel"]]
         traffic, source = self._pmc_traffic(pair), None

@@ -718,7 +718,9 @@ class Engine:
             handles = (C.POINTER(_hip.RectPlan) * len(cycle))(*[plan.handle for plan in cycle])
             _hip.check(self.lib.qp_adi_rect_pr_cycle(handles, len(cycle), _ptr(u), _ptr(R), self.stream),
                        "qp_adi_rect_pr_cycle")
-            self.stencil(op, u, res, -1.0, 1.0, 1.0, 0.0, rin=R, cr=1.0, norm_out=norms[1:2])
+            # the check needs the NORM of the residual only (its plane is formed again by the polishing loop if the check
+            # fails): no output plane
+            self.stencil(op, u, None, -1.0, 1.0, 1.0, 0.0, rin=R, cr=1.0, norm_out=norms[1:2])
             scale, err = (float(x) for x in norms.cpu())
             if not np.isfinite(err):
                 raise FloatingPointError("exact-CN iteration diverged (non-finite residual)")
@@ -890,7 +892,7 @@ class Engine:
                        "register" if (kernel == "auto" and structure is not None and (nclass == 1 or classes_ok)
                                       and bool(self.lib.qp_collision_register_kernel_available(ne))) else "wave")
         h["fast"] = h["kernel"] != "generic"      # no accumulator planes needed
-        # one-pass kernel (ne = 32, 40, 50): the kernel tables once more in (anti)diagonal-major order (qpsim_hip.h)
+        # one-pass kernel (ne = 30, 32, 40, 50): the kernel tables once more in (anti)diagonal-major order (qpsim_hip.h)
         h["ks0_diag"] = h["kr0_anti2"] = None
         if (h["kernel"] == "register" and nclass == 1 and symmetric and bool(self.lib.qp_collision_onepass_available(ne))):
             if ks0 is not None:
