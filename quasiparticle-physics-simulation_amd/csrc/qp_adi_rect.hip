@@ -1153,24 +1153,26 @@ int qp_adi_rect_combine(qp_adi_rect_plan* plan, const double* u, const double* r
   hipStream_t stream = (hipStream_t)stream_;
   const RectView& v = plan->view;
   // one band of 8 rows (row lengths that are multiples of 4) or one row per block and trip
-  constexpr int RB = 16;
-  long blocks = (v.d.nx & 3) == 0 ? (long)v.d.nfield * ((v.d.ny + RB - 1) / RB) * ((v.d.nx + 1023) / 1024)
+  // rows per band: 8 (two halo rows per band) on large grids; 4 on small ones, where 8-row bands leave most CUs without a
+  // block (1024^2: 128 blocks).  16-row bands were measured at 4096^2: no gain (the kernel is not bound by the halo rows).
+  const bool small = (long)v.d.nfield * plan->ncell < (1L << 22);
+  const int rb = small ? 4 : 8;
+  long blocks = (v.d.nx & 3) == 0 ? (long)v.d.nfield * ((v.d.ny + rb - 1) / rb) * ((v.d.nx + 1023) / 1024)
                                   : (long)v.d.nfield * v.d.ny;
   if (blocks > 1024) blocks = 1024;         // = the partial slots of the reduction workspace
-  // only the 4-cells-per-thread branch makes 16-byte accesses (per-field views with odd ncell take the row branch)
   QP_REQUIRE((v.d.nx & 3) != 0 || ((uintptr_t)u | (uintptr_t)out | (uintptr_t)rin) % 16 == 0,
              "u, rin, out must be 16-byte aligned when nx is a multiple of 4");
   RectSides g{plan->bc_diag[0], plan->bc_diag[1], plan->bc_diag[2], plan->bc_diag[3],
               plan->bc_src[0], plan->bc_src[1], plan->bc_src[2], plan->bc_src[3]};
   if (v.d.nx == 1) { g.dr = 0.0; g.sr = 0.0; }   // one column: rect_side_terms folds both x-faces into the "left" slot
   if (v.d.ny == 1) { g.dd = 0.0; g.sd = 0.0; }
-  if (out)
-    hipLaunchKernelGGL((rect_combine_kernel<true, RB>), dim3((unsigned)blocks), dim3(256), 0, stream, v.d.ny, v.d.nx, v.d.nfield,
-                       (const double*)plan->d_alpha, g, u, rin, out, c0, cx, cy, cs, cr,
-                       norm_out ? (double*)workspace : nullptr);
-  else
-    hipLaunchKernelGGL((rect_combine_kernel<false, RB>), dim3((unsigned)blocks), dim3(256), 0, stream, v.d.ny, v.d.nx, v.d.nfield,
-                       (const double*)plan->d_alpha, g, u, rin, out, c0, cx, cy, cs, cr, (double*)workspace);
+  double* part = (out == nullptr || norm_out) ? (double*)workspace : nullptr;
+#define QP_COMBINE(STORE, RB)                                                                                              \
+  hipLaunchKernelGGL((rect_combine_kernel<STORE, RB>), dim3((unsigned)blocks), dim3(256), 0, stream, v.d.ny, v.d.nx,      \
+                     v.d.nfield, (const double*)plan->d_alpha, g, u, rin, out, c0, cx, cy, cs, cr, part)
+  if (out) { if (small) QP_COMBINE(true, 4); else QP_COMBINE(true, 8); }
+  else { if (small) QP_COMBINE(false, 4); else QP_COMBINE(false, 8); }
+#undef QP_COMBINE
   if (norm_out) absmax_finish((const double*)workspace, (int)blocks, norm_out, stream);
   return check_launch("qp_adi_rect_combine");
 }
