@@ -138,7 +138,8 @@ typedef struct qp_collision_tables {
    * with kr_amp = (1/tau_r) ((Ei+Ej)/kTc)^2 / kTc, ks_amp = (1/tau_s) (Ei-Ej)^2 / kTc^3 (zero diagonal),
    * pair_inv = 1 / max(Ei Ej, 1e-30).  When gap_sq[nclass] and pair_inv are given (kr_amp / ks_amp per enabled process),
    * the register-resident kernel serves gap classes too (qp_collision_register_kernel_classes(ne)): it forms K per pixel from these three shared tables
-   * instead of reading per-class tables.  All NULL: gap classes run the one-wave-per-pixel kernel. */
+   * instead of reading per-class tables; at ne = 50 with at most 16 classes that is the one-pass kernel as well (the tables
+   * staged in LDS, K formed per lane).  All NULL: gap classes run the one-wave-per-pixel kernel. */
   const double* gap_sq;
   const double* kr_amp;
   const double* ks_amp;

@@ -137,6 +137,9 @@ bool collision_onepass_dispatch(const qp_collision_tables& tb, double* stash, co
                                 const double* sin_, double* sout, double* ph, double dE, double dt, bool s, bool r, bool u,
                                 hipStream_t stream);
 
+bool collision_onepass_dispatch_classes(const qp_collision_tables& tb, double* stash, const uint8_t* flags, long ncell,
+                                        const double* sin_, double* sout, double* ph, double dE, double dt, bool s, bool r,
+                                        bool u, hipStream_t stream);
 int collision_onepass_supported(int ne);
 int collision_pair_supported(int ne);
 bool collision_pair_dispatch(const qp_collision_tables& tb, const uint8_t* flags, long ncell, const double* sin_, double* sout,
@@ -207,7 +210,15 @@ static int collision_step_impl(const qp_collision_tables* t, const uint8_t* flag
                                   state_in, state_out, phonon, dE, dt, enable_recombination, enable_scattering,
                                   update_phonons, guard, guard_floor, guard_done, (hipStream_t)stream))
     return qp::check_launch("qp_collision_step(fast)");
-  // gap classes with the separable kernel tables: register kernel that forms K per pixel
+  // gap classes with the separable kernel tables: the one-pass kernel where it exists ...
+  if (t->diag_bin && t->nclass > 1 && qp::collision_onepass_supported(t->ne) &&
+      !(t->flags & (QP_COLL_FORCE_GENERIC | QP_COLL_FORCE_WAVE)) && shared_ok && ncell < (1L << 28) &&
+      qp::collision_onepass_dispatch_classes(*t, ph_scratch, flags, (long)ncell, state_in, state_out, phonon, dE, dt,
+                                             enable_scattering && t->ks0, enable_recombination && t->kr0,
+                                             update_phonons && ((enable_scattering && t->ks0) || (enable_recombination && t->kr0)),
+                                             (hipStream_t)stream))
+    return qp::check_launch("qp_collision_step(one pass, gap classes)");
+  // ... else the register kernels that form K per pixel
   if (t->diag_bin && t->nclass > 1 && t->gap_sq && t->pair_inv && t->cls &&
       (!(enable_recombination && t->kr0) || t->kr_amp) && (!(enable_scattering && t->ks0) || t->ks_amp) &&
       !(t->flags & (QP_COLL_FORCE_GENERIC | QP_COLL_FORCE_WAVE)) && shared_ok &&

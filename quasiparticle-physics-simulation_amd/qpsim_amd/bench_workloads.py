@@ -347,7 +347,9 @@ class CoupledWorkload:
         pairs = self.ne * self.ne
         flops = updates * 26.0 * pairs * self.npix     # ~26 NE^2 flop per pixel-update
         tflops = flops / per_call / 1e12
-        onepass = (self.tab.get("ks0_diag") is not None or self.tab.get("kr0_anti2") is not None) \
+        classes_onepass = (self.tab.get("gap_sq") is not None and self.ne == 50
+                           and int(self.tab["struct"].nclass) <= 16)      # qp_collision_onepass.hip: gap-class form
+        onepass = (self.tab.get("ks0_diag") is not None or self.tab.get("kr0_anti2") is not None or classes_onepass) \
             and os.environ.get("QPSIM_COLL_ONEPASS", "1") != "0"
         kernel = {"register": ("collision_pair_kernel (two half-steps per launch, intermediate state in registers)" if pair else
                                "collision_onepass_kernel (one launch, tables staged in LDS)" if onepass else

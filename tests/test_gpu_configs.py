@@ -480,6 +480,49 @@ def test_one_pass_ne50_kernel_equals_the_split_kernels_on_a_ragged_masked_grid(m
         assert np.array_equal(outs["1"][1], ph)
 
 
+@pytest.mark.parametrize("combo", [(True, True, True), (True, True, False), (True, False, True), (False, True, True)])
+def test_one_pass_ne50_gap_class_kernel_equals_the_split_kernels(monkeypatch, combo):
+    """Non-uniform gap at NE = 50 (per-pixel tables of solver.py:1203-1232 as 5 gap classes, one of them unused): the
+    one-launch kernel forms K per lane from the amplitude tables staged in LDS (compact (anti)diagonal order in the phonon
+    phase, per-class rho rows read per lane); against the three-launch gap-class path on a ragged masked grid whose blocks
+    mix classes lane by lane."""
+    from qpsim_amd import tables as T
+    from qpsim_amd.engine import CompiledGeometry, Engine, link_flags
+    en_r, en_s, upd = combo
+    ne = 50
+    rng = np.random.default_rng(23)
+    mask = rng.random((23, 37)) > 0.2
+    z = np.zeros(mask.shape)
+    eng = Engine(CompiledGeometry(mask, 1.0, link_flags(mask), z, z, z, z))
+    n = int(mask.sum())
+    gaps = np.array([180.0, 171.0, 165.5, 176.25, 150.0])
+    E, dE = T.build_energy_grid(180.0, 1.0, 10.0, ne)
+    om, idx_d, idx_s, sg = T.build_phonon_frequency_map(E)
+    rho = np.stack([T.dynes_density_of_states(E, g, 0.1) for g in gaps])
+    kr = np.stack([T.recombination_kernel_base(E, g, 500.0, 1.2) for g in gaps])
+    ks = np.stack([T.scattering_kernel_base(E, g, 400.0, 1.2) for g in gaps])
+    cls = rng.integers(0, 4, size=n)
+    state = rng.random((ne, n)) * rho[cls].T * rng.choice([1e-5, 1e-2, 0.5, 0.95], size=n)[None, :]
+    ph = T.thermal_phonon_occupation(om, 0.3)[:, None] * (0.5 + rng.random((om.size, n)))
+    tab = eng.make_collision_tables(kr, ks, rho, idx_d, idx_s, sg, cls,
+                                    gap_params=dict(E=E, gaps=gaps, tau_r=500.0, tau_s=400.0, T_c=1.2))
+    assert tab["kernel"] == "register"
+    outs = {}
+    for onepass in ("1", "0"):
+        monkeypatch.setenv("QPSIM_COLL_ONEPASS", onepass)
+        s_in, p_dev = eng.upload_packed(state), eng.upload_packed(ph)
+        s_out = eng.empty(ne, eng.ncell)
+        s_out.fill_(-7.0)
+        eng.collide(tab, s_in, s_out, p_dev, dE, 0.37, en_r, en_s, upd)
+        outs[onepass] = (eng.download_packed(s_out), eng.download_packed(p_dev), s_out.cpu().numpy(), p_dev.cpu().numpy())
+    assert rel_err(outs["1"][0], outs["0"][0]) < 1e-13
+    assert rel_err(outs["1"][1], outs["0"][1]) < (1e-10 if upd else 1e-300)
+    hole = ~mask.reshape(-1)
+    assert np.all(outs["1"][2][:, hole] == 0.0) and np.all(outs["1"][3][:, hole] == 0.0)
+    if not upd:
+        assert np.array_equal(outs["1"][1], ph)
+
+
 @pytest.mark.parametrize("ne,combo", [(12, (True, True, True)), (12, (True, False, False)), (12, (False, True, True)),
                                       (8, (True, True, True)), (8, (True, True, False)), (16, (True, True, True)), (5, (False, True, True))])
 def test_double_half_step_kernel_equals_two_calls_bit_for_bit(ne, combo):
