@@ -31,6 +31,7 @@ traffic adi1024 "--workload adi1024 --steps 100 --warmup 10"
 traffic adi2048 "--workload adi2048 --steps 50 --warmup 5"
 stats coupled1024ne50 "--workload coupled1024ne50 --steps 6 --warmup 2"
 traffic coupled1024ne50 "--workload coupled1024ne50 --steps 4 --warmup 1"
+stats coupled1024ne50gap4 "--workload coupled1024ne50gap4 --steps 6 --warmup 2"
 stats c4 "--workload c4 --steps 20 --warmup 3"
 stats cn4096 "--workload cn4096 --steps 20 --warmup 3"
 cd $R && cat $out/*_pmc.txt | cut -c1-170
