@@ -474,6 +474,44 @@ def test_fast_collision_kernel_matches_generic_and_oracle(O, ne, fmax, en_r, en_
     assert rel_err(outs[0][0], s_ref) < 2e-11 and rel_err(outs[0][1], p_ref) < (2e-11 if ne <= 16 else PHONON_TOL)
 
 
+@pytest.mark.parametrize("ne,fmax", [(12, 3.0), (50, 10.0)])
+@pytest.mark.parametrize("dt", [0.0, 1e-7, 3e-3, 25.0])
+def test_collision_update_over_the_range_of_rate_times_step(O, ne, fmax, dt):
+    """The exponential updates (solver.py:640-665, :686-700) over the regimes of x = rate * dt: dt = 0 (state returned
+    unchanged - x = 0 with finite rates, where the small-|x| path of the NE < 30 kernels has no reciprocal), |x| ~ 1e-8
+    (the reference's e^x - 1 is rounding-dominated there: the kernels reproduce that rounding instead of the closed form),
+    the small-|x| polynomial path proper, and |x| >> 1/8 (general path, clip to +-80; waves mix both paths pixel by pixel
+    through the occupation levels).  Against the oracle at the tolerances of the other collision tests."""
+    from qpsim_amd import tables as T
+    from qpsim_amd.engine import CompiledGeometry, Engine, link_flags
+    rng = np.random.default_rng(ne + 101)
+    mask = rng.random((9, 31)) > 0.2
+    z = np.zeros(mask.shape)
+    eng = Engine(CompiledGeometry(mask, 1.0, link_flags(mask), z, z, z, z))
+    n = int(mask.sum())
+    E, dE = T.build_energy_grid(180.0, 1.0, fmax, ne)
+    om, idx_d, idx_s, sg = T.build_phonon_frequency_map(E)
+    rho = T.dynes_density_of_states(E, 180.0, 0.1)
+    kr, ks = T.recombination_kernel_base(E, 180.0, 500.0, 1.2), T.scattering_kernel_base(E, 180.0, 400.0, 1.2)
+    state = rng.random((ne, n)) * rho[:, None] * rng.choice([1e-9, 1e-5, 1e-2, 0.5, 0.95], size=n)[None, :]
+    ph = T.thermal_phonon_occupation(om, 0.3)[:, None] * (0.5 + rng.random((om.size, n)))
+    tab = eng.make_collision_tables(kr[None], ks[None], rho[None], idx_d, idx_s, sg)
+    assert tab["kernel"] == "register"
+    s_in, p_dev = eng.upload_packed(state), eng.upload_packed(ph)
+    s_out = eng.empty(ne, eng.ncell)
+    eng.collide(tab, s_in, s_out, p_dev, dE, dt, True, True, True)
+    got_s, got_p = eng.download_packed(s_out), eng.download_packed(p_dev)
+    assert np.all(np.isfinite(got_s)) and np.all(np.isfinite(got_p))
+    if dt == 0.0:
+        assert np.array_equal(got_s, state) and np.array_equal(got_p, ph)
+        return
+    tables = {"rho": rho[None], "Kr0": kr[None], "Ks0": ks[None], "cls": np.zeros(n, dtype=int), "idx_diff": idx_d,
+              "idx_sum": idx_s, "sign": sg, "dE": dE}
+    s_ref, p_ref = state.copy(), ph.copy()
+    O.collision_step(s_ref, p_ref, tables, dt, en_r=True, en_s=True, update_phonons=True)
+    assert rel_err(got_s, s_ref) < 2e-11 and rel_err(got_p, p_ref) < (2e-11 if ne <= 16 else PHONON_TOL)
+
+
 @pytest.mark.parametrize("ne,fmax", [(12, 5.0), (18, 10.0), (24, 4.0), (40, 5.0), (50, 5.0)])
 @pytest.mark.parametrize("en_r,en_s,upd", PROCESS_COMBOS)
 def test_register_collision_kernel_with_merged_phonon_bins(O, ne, fmax, en_r, en_s, upd):
